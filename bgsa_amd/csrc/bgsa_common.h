@@ -1,0 +1,84 @@
+// bgsa_common.h — shared host/device helpers of the gfx950 backend (internal, not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bgsa_hip.h"
+
+namespace bgsa {
+
+constexpr int kLanes = HIP_V_NUM;      // one subject per lane of a 64-wide wavefront
+constexpr int kChars = BGSA_CHAR_NUM;  // A C G T N
+constexpr int kWavesPerBlock = 4;      // 256-thread workgroups: one wave per SIMD of a CU
+constexpr int kMaxWords = 32;          // longest subject kept entirely in VGPRs: 32 x 32 = 1024 bp
+
+void set_error(const char *what, hipError_t e, const char *file, int line);
+void set_error_text(const char *text);
+
+#define BGSA_HIP_TRY(expr)                                              \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) {                                         \
+            ::bgsa::set_error(#expr, e_, __FILE__, __LINE__);           \
+            return BGSA_HIP_EHIP;                                       \
+        }                                                               \
+    } while (0)
+
+// Launchers implemented in the per-algorithm .hip files.  All pointers are device pointers.
+int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+                 int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+                 hipStream_t stream);
+const char *myers_kernel_name(int word_num);
+
+int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
+                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, int k,
+                  hipStream_t stream);
+const char *banded_kernel_name(int word_num);
+
+int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+                  hipStream_t stream);
+const char *bitpal_kernel_name(int word_num);
+
+int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
+                      int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream);
+int launch_map_queries(char *d_content, int64_t bytes, hipStream_t stream);
+
+// ---- device helpers ---------------------------------------------------------------------------
+
+// A wave-uniform byte string read through the scalar data cache, four characters per fetch.
+// Query rows have stride len+1 (reference cal_cpu.c:78), so a row may start at any byte
+// alignment: the fetch is the aligned dword pair that covers the next four bytes.  Everything
+// stays in SGPRs as long as the row pointer is wave-uniform.
+struct UniformBytes {
+    const uint32_t *words;  // row start rounded down to a dword
+    uint32_t shift;         // 8 * (row start & 3)
+    uint32_t window;        // the characters fetched but not yet consumed, next one in bits 7:0
+
+    __device__ __forceinline__ explicit UniformBytes(const char *row)
+    {
+        uintptr_t a = reinterpret_cast<uintptr_t>(row);
+        words = reinterpret_cast<const uint32_t *>(a & ~static_cast<uintptr_t>(3));
+        shift = static_cast<uint32_t>(a & 3) * 8;
+        window = 0;
+    }
+    // Call when (r & 3) == 0; `remaining` = characters of the row not yet fetched (>= 1).
+    __device__ __forceinline__ void refill(int r, int remaining)
+    {
+        const uint32_t lo = words[r >> 2];
+        uint32_t hi = 0;
+        const int need_bits = 8 * (remaining < 4 ? remaining : 4);
+        if (shift + need_bits > 32) hi = words[(r >> 2) + 1];  // only when the bytes straddle
+        window = static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> shift);
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        uint32_t c = window & 0xffu;
+        window >>= 8;
+        return c;
+    }
+};
+
+}  // namespace bgsa

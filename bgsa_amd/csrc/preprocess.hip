@@ -1,0 +1,185 @@
+// preprocess.hip — subject preprocess (ASCII rows -> per-lane Peq match masks) and query mapping.
+//
+// Replaces <arch>_handle_reads (reference original/BGSA_CPU/global.c:25-70; banded form
+// banded/BGSA_CPU/global.c:25-84) and the in-place query map of get_ref_from_file
+// (original/BGSA_CPU/file.c:134-139), both as a host routine (the reference's seam) and as GPU
+// kernels so the host only ships raw rows.
+//
+// Layout produced, for every group of 64 consecutive subjects:
+//     peq[group][char 0..4][word 0..word_num-1][lane 0..63]
+// Global Myers / BitPAl: 32-bit words, bit (p mod D) of word (p div D) set iff subject[p] maps to
+// `char`, D = data bits per word (32 for Myers, 31 or 32 for BitPAl — see bitpal.hip).
+// Banded: 64-bit words; word 0 = first k characters at bits k+1..2k, words 1.. = characters
+// k, k+1, ... 64 per word (banded/BGSA_CPU/global.c:44-82).
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "bgsa_common.h"
+
+namespace bgsa {
+
+// init_mapping_table, reference original/BGSA_CPU/global.c:9-15: A C G T N -> 0..4, rest -> 0.
+__host__ __device__ __forceinline__ uint32_t map_char(uint32_t ch)
+{
+    return ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : 0u;
+}
+
+// ---- global layout (Myers / BitPAl) -------------------------------------------------------------
+
+// One lane builds all words of its own subject.  Lanes read their rows byte by byte (stride
+// len+1 across lanes, sequential per lane, so every 128-B line fetched is fully consumed from L1
+// over the following iterations) and write coalesced 256-B rows of the block.
+__global__ __launch_bounds__(256) void preprocess_global_kernel(const char *__restrict__ rows,
+                                                                uint32_t *__restrict__ peq, int len,
+                                                                long long read_count, int word_num,
+                                                                int data_bits)
+{
+    const long long subject = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (subject >= read_count) return;
+    const long long group = subject >> 6;
+    const int lane = static_cast<int>(subject & 63);
+    const char *row = rows + subject * (len + 1);
+    uint32_t *dst = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+    for (int w = 0; w < word_num; w++) {
+        uint32_t m[kChars] = {0, 0, 0, 0, 0};
+        const int base = w * data_bits;
+        const int n = min(data_bits, len - base);
+        for (int b = 0; b < n; b++) {
+            const uint32_t c = map_char(static_cast<uint8_t>(row[base + b]));
+#pragma unroll
+            for (uint32_t cc = 0; cc < kChars; cc++) m[cc] |= static_cast<uint32_t>(c == cc) << b;
+        }
+#pragma unroll
+        for (int cc = 0; cc < kChars; cc++) dst[(cc * word_num + w) * kLanes] = m[cc];
+    }
+}
+
+// ---- banded layout ------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void preprocess_banded_kernel(const char *__restrict__ rows,
+                                                                long long avail,
+                                                                uint64_t *__restrict__ peq, int len,
+                                                                long long read_count, int word_num,
+                                                                int k)
+{
+    const long long subject = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (subject >= read_count) return;
+    const long long group = subject >> 6;
+    const int lane = static_cast<int>(subject & 63);
+    const long long off = subject * (len + 1);
+    const char *row = rows + off;
+    const long long readable = avail - off;  // the reference runs k characters past the row
+    uint64_t *dst = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+    for (int w = 0; w < word_num; w++) {
+        uint64_t m[kChars] = {0, 0, 0, 0, 0};
+        if (w == 0) {
+            for (int p = 0; p < k; p++) {
+                const uint32_t ch = p < readable ? static_cast<uint8_t>(row[p]) : '\n';
+                const uint32_t c = map_char(ch);
+#pragma unroll
+                for (uint32_t cc = 0; cc < kChars; cc++) m[cc] |= static_cast<uint64_t>(c == cc) << (k + 1 + p);
+            }
+        } else {
+            const int base = (w - 1) * 64;
+            const int n = min(64, len - base);
+            for (int b = 0; b < n; b++) {
+                const int p = k + base + b;
+                const uint32_t ch = p < readable ? static_cast<uint8_t>(row[p]) : '\n';
+                const uint32_t c = map_char(ch);
+#pragma unroll
+                for (uint32_t cc = 0; cc < kChars; cc++) m[cc] |= static_cast<uint64_t>(c == cc) << b;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < kChars; cc++) dst[(cc * word_num + w) * kLanes] = m[cc];
+    }
+}
+
+// ---- query map ------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void map_queries_kernel(char *content, long long bytes)
+{
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= bytes) return;
+    const uint8_t ch = static_cast<uint8_t>(content[i]);
+    if (ch != '\n') content[i] = static_cast<char>(map_char(ch));
+}
+
+int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
+                      int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream)
+{
+    if (read_count == 0) return BGSA_HIP_OK;
+    const unsigned blocks = static_cast<unsigned>((read_count + 255) / 256);
+    if (algo == BGSA_ALGO_BANDED) {
+        hipLaunchKernelGGL(preprocess_banded_kernel, dim3(blocks), dim3(256), 0, stream, d_rows,
+                           static_cast<long long>(avail_bytes), reinterpret_cast<uint64_t *>(d_peq),
+                           len, static_cast<long long>(read_count), word_num, k);
+    } else {
+        hipLaunchKernelGGL(preprocess_global_kernel, dim3(blocks), dim3(256), 0, stream, d_rows,
+                           d_peq, len, static_cast<long long>(read_count), word_num,
+                           algo == BGSA_ALGO_BITPAL ? 31 : 32);
+    }
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+int launch_map_queries(char *d_content, int64_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return BGSA_HIP_OK;
+    const unsigned blocks = static_cast<unsigned>((bytes + 255) / 256);
+    hipLaunchKernelGGL(map_queries_kernel, dim3(blocks), dim3(256), 0, stream, d_content,
+                       static_cast<long long>(bytes));
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+// ---- host routine behind hip_handle_reads -------------------------------------------------------
+
+void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint32_t *result_reads,
+                       int word_num, int64_t read_count, int k, int threads)
+{
+    const int64_t n_groups = read_count / kLanes;
+    if (threads < 1) threads = 1;
+    threads = static_cast<int>(std::min<int64_t>(threads, std::max<int64_t>(n_groups, 1)));
+    auto work = [&](int t) {
+        for (int64_t g = t; g < n_groups; g += threads) {
+            for (int lane = 0; lane < kLanes; lane++) {
+                const int64_t off = (g * kLanes + lane) * static_cast<int64_t>(len + 1);
+                const char *row = rows + off;
+                if (algo == BGSA_ALGO_BANDED) {
+                    uint64_t *dst = reinterpret_cast<uint64_t *>(result_reads) +
+                                    static_cast<size_t>(g) * kChars * word_num * kLanes + lane;
+                    const int64_t readable = avail - off;
+                    for (int p = 0; p < k; p++) {
+                        const uint32_t ch = p < readable ? static_cast<uint8_t>(row[p]) : '\n';
+                        if (word_num > 0) dst[(map_char(ch) * word_num) * kLanes] |= 1ULL << (k + 1 + p);
+                    }
+                    for (int i = 0; i < len; i++) {
+                        const int w = 1 + i / 64;
+                        if (w >= word_num) break;
+                        const int p = k + i;
+                        const uint32_t ch = p < readable ? static_cast<uint8_t>(row[p]) : '\n';
+                        dst[(map_char(ch) * word_num + w) * kLanes] |= 1ULL << (i % 64);
+                    }
+                } else {
+                    const int bits = algo == BGSA_ALGO_BITPAL ? 31 : 32;
+                    uint32_t *dst = result_reads + static_cast<size_t>(g) * kChars * word_num * kLanes + lane;
+                    for (int p = 0; p < len; p++) {
+                        const uint32_t c = map_char(static_cast<uint8_t>(row[p]));
+                        dst[(c * word_num + p / bits) * kLanes] |= 1u << (p % bits);
+                    }
+                }
+            }
+        }
+    };
+    if (threads == 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace bgsa

@@ -1,0 +1,162 @@
+/*
+ * bgsa_hip.h — C ABI of the MI355X (gfx950) backend for BGSA's all-pairs bit-parallel global
+ * alignment hot path.  Everything here is `extern "C"`, plain pointers and sizes.
+ *
+ * The library is a drop-in "ISA backend" in the sense of the reference's original/BGSA_<ARCH>
+ * directories: it exports the same three seams every backend exports —
+ *
+ *     <arch>_handle_reads      (reference original/BGSA_CPU/global.h:24,  global.c:25-70)
+ *     align_<arch>             (reference original/BGSA_CPU/align_core.h:8, align_core.c:19-148)
+ *     <arch>_cal_align_score   (reference original/BGSA_CPU/cal.h:48,      cal_cpu.c:43-85)
+ *
+ * with <arch> = hip, plus the five scoring ints every align_core.c defines
+ * (align_core.c:13-17) and the alphabet map (global.c:7-15).  Those entry points take HOST
+ * buffers, exactly like the reference's.  Underneath them sits a device-resident layer
+ * (bgsa_hip_*_dev) that a pipeline driver uses to keep subjects and scores in HBM between
+ * calls, the way the reference's KNC backend keeps them on the coprocessor
+ * (original/BGSA_KNC/cal_mic.c:86-154, 348-356).
+ *
+ * Error convention: the BGSA-surface functions are `void` and print + exit(1) on failure, like
+ * the reference (file.c:13-16).  The bgsa_hip_* functions return 0 on success or a negative
+ * BGSA_HIP_E* code and never exit.
+ */
+#ifndef BGSA_HIP_H
+#define BGSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- config.h-style constants (reference original/BGSA_CPU/config.h:6-27) ------------------ */
+#define BGSA_CHAR_NUM 5            /* CHAR_NUM: A C G T N planes */
+#define HIP_V_NUM 64               /* subjects per group = lanes of one wavefront */
+#define HIP_WORD_SIZE 32           /* bits per bit-vector word; all 32 carry data (full_bits = 1) */
+#define HIP_BANDED_WORD_SIZE 64    /* banded path keeps the reference's 64-bit window */
+#define HIP_MAX_ERROR 127          /* MAX_ERROR, banded/BGSA_CPU/config.h:19 */
+typedef uint32_t hip_read_t;       /* element of the preprocessed Peq blocks */
+typedef uint32_t hip_data_t;       /* element of the (unused) dvdh_bit_mem scratch */
+typedef int16_t hip_write_t;       /* common_write_t of original/ (Myers, BitPAl) */
+typedef int8_t hip_banded_write_t; /* common_write_t of banded/ */
+
+/* seq_t, reference original/BGSA_CPU/global.h:9-16 (same field order and types). */
+#ifndef BGSA_HAVE_SEQ_T
+#define BGSA_HAVE_SEQ_T
+typedef struct _seq_t {
+    int len;
+    int64_t size;
+    int64_t count;
+    int extra_size;
+    int extra_count;
+    char *content;
+} seq_t;
+#endif
+
+/* ---- algorithm selection -------------------------------------------------------------------
+ * The reference bakes the algorithm into the generated align_core.c; one backend directory =
+ * one algorithm.  This library carries all three and switches at run time. */
+enum {
+    BGSA_ALGO_MYERS = 0,  /* unit-cost global edit distance, result = -distance (int16) */
+    BGSA_ALGO_BANDED = 1, /* banded Myers filter, result = band distance or 127 (int8) */
+    BGSA_ALGO_BITPAL = 2, /* BitPAl packed match 2 / mismatch -3 / gap -5 (int16) */
+};
+
+/* The five ints every align_core.c exports (reference original/BGSA_CPU/align_core.c:13-17);
+ * bgsa_hip_select_algorithm() keeps them consistent with the selected algorithm. */
+extern int match_score;
+extern int mismatch_score;
+extern int gap_score;
+extern int dvdh_len;
+extern int full_bits;
+/* -k of banded/BGSA_CPU (banded/BGSA_CPU/global.h:43, main.c:43,62-64). */
+extern int threshold;
+/* Host threads used by hip_handle_reads (reference global `cpu_threads`, main.c:16,38). */
+extern int cpu_threads;
+
+/* Alphabet map (reference original/BGSA_CPU/global.c:7-15). */
+extern uint32_t mapping_table[128];
+void init_mapping_table(void);
+
+/* 64-byte aligned host allocation (reference global.c:17-23). */
+void *malloc_mem(uint64_t size);
+void free_mem(void *mem);
+
+int bgsa_hip_select_algorithm(int algo);
+int bgsa_hip_current_algorithm(void);
+
+/* word_num for the selected algorithm (what cal_<arch>.c computes at cal_cpu.c:252-256, banded
+ * cal_cpu.c:253-254). */
+int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k);
+/* Peq elements (hip_read_t) per group of HIP_V_NUM subjects = BGSA_CHAR_NUM * word_num *
+ * HIP_V_NUM * (sizeof element / 4). */
+size_t bgsa_hip_group_words(int algo, int word_num);
+
+/* ---- BGSA backend surface (host buffers) --------------------------------------------------- */
+
+/* ASCII rows -> Peq blocks, layout [group][char 0..4][word][lane 0..63]
+ * (replaces cpu_handle_reads, reference original/BGSA_CPU/global.c:25-70; banded form
+ * banded/BGSA_CPU/global.c:25-84).  result_reads must be zeroed by the caller (cal_cpu.c:273)
+ * and read_count must be a multiple of HIP_V_NUM (file.c:84-112 pads with all-'N' reads). */
+void hip_handle_reads(seq_t *read_seq, hip_read_t *result_reads, int word_num,
+                      int64_t read_start, int64_t read_count);
+
+/* One mapped query against chunk_read_num consecutive groups
+ * (replaces align_cpu, reference original/BGSA_CPU/align_core.c:19-148).
+ * results[(result_index + k) * HIP_V_NUM + lane].  dvdh_bit_mem is accepted and ignored. */
+void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_num,
+               int chunk_read_num, int result_index, hip_write_t *results,
+               hip_data_t *dvdh_bit_mem);
+
+/* All queries [ref_start, ref_end) x all read_count subjects of the bucket, row-major
+ * [ref][read] results (replaces cpu_cal_align_score, reference cal_cpu.c:43-85).
+ * For BGSA_ALGO_BANDED align_results is really hip_banded_write_t*. */
+void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_t *align_results,
+                         int ref_len, int ref_count, int read_len, int read_count, int ref_start,
+                         int ref_end, int word_num, int chunk_read_num, hip_data_t *dvdh_bit_mem);
+
+/* ---- device-resident layer ----------------------------------------------------------------- */
+
+#define BGSA_HIP_OK 0
+#define BGSA_HIP_EINVAL (-1)      /* bad argument (null pointer, negative size, misaligned count) */
+#define BGSA_HIP_EUNSUPPORTED (-2) /* length / threshold outside what the kernels cover */
+#define BGSA_HIP_EHIP (-3)        /* a HIP runtime call failed; text via bgsa_hip_last_error() */
+
+const char *bgsa_hip_last_error(void);
+int bgsa_hip_device_count(void);
+int bgsa_hip_set_device(int device);
+
+/* Plain device memory helpers so C hosts need no HIP headers. */
+int bgsa_hip_malloc(void **dptr, size_t bytes);
+int bgsa_hip_free(void *dptr);
+int bgsa_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int bgsa_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int bgsa_hip_memset(void *dst, int value, size_t bytes, void *stream);
+int bgsa_hip_stream_synchronize(void *stream);
+
+/* Subject preprocess ON the GPU: d_rows = read_count rows of (len+1) ASCII bytes in device
+ * memory -> d_peq in the layout above.  read_count must be a multiple of HIP_V_NUM.
+ * `avail_bytes` = readable bytes of d_rows (banded over-read guard).  Overwrites d_peq. */
+int bgsa_hip_handle_reads_dev(int algo, const char *d_rows, int64_t avail_bytes, int len,
+                              int64_t read_count, int word_num, int k, hip_read_t *d_peq,
+                              void *stream);
+
+/* Query bytes -> 0..4 in place on the device ('\n' kept), get_ref_from_file's map
+ * (reference original/BGSA_CPU/file.c:134-139). */
+int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream);
+
+/* The hot path.  d_content = mapped query rows, stride ref_len+1 (reference cal_cpu.c:78);
+ * d_peq = Peq blocks of read_count subjects; d_results = [ref_end-ref_start][read_count]
+ * (int16, or int8 for banded).  All pointers are device pointers; asynchronous on `stream`. */
+int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read_t *d_peq,
+                                 void *d_results, int ref_len, int read_len, int64_t read_count,
+                                 int ref_start, int ref_end, int word_num, int k, void *stream);
+
+/* Name of the kernel the previous call would launch for these shapes (for profiles/bench). */
+const char *bgsa_hip_kernel_name(int algo, int word_num);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGSA_HIP_H */

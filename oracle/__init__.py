@@ -224,7 +224,7 @@ def parse_gcups(stdout: str) -> dict:
     (reference original/BGSA_CPU/cal_cpu.c:459-475)."""
     out = {}
     for line in stdout.splitlines():
-        line = line.strip()
+        line = " ".join(line.split())  # BGSA_SSE prints "cal   GCUPS is"
         if line.startswith("cal GCUPS is"):
             out["cal_gcups"] = float(line.split()[-1])
         elif line.startswith("Total GCUPS is"):

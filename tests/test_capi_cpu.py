@@ -1,0 +1,102 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every declared symbol, and its host
+logic (word counts, host preprocess layout) is right.  No compute entry point is called."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import bgsa_amd as B
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not B.LIB_PATH.exists():
+        B.build_library()
+    return B.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    names = B.declared_symbols()
+    assert len(names) >= 20
+    for fn in ("hip_handle_reads", "align_hip", "hip_cal_align_score", "init_mapping_table",
+               "bgsa_hip_cal_align_score_dev", "bgsa_hip_handle_reads_dev"):
+        assert fn in names
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/bgsa_hip.h but not exported: {missing}"
+    for var in ("match_score", "mismatch_score", "gap_score", "dvdh_len", "full_bits", "threshold",
+                "cpu_threads", "mapping_table"):
+        ctypes.c_int.in_dll(L, var)
+
+
+def test_algorithm_globals_follow_selection(L):
+    # the five ints of align_core.c:13-17 track the selected algorithm
+    assert L.bgsa_hip_select_algorithm(B.ALGO_BITPAL) == 0
+    assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [2, -3, -5]
+    assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+    assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [0, -1, -1]
+    assert ctypes.c_int.in_dll(L, "full_bits").value == 1
+    assert L.bgsa_hip_select_algorithm(99) != 0
+    assert L.bgsa_hip_current_algorithm() == B.ALGO_MYERS
+
+
+def test_word_num(L):
+    assert B.word_num(B.ALGO_MYERS, 150, 150) == 5
+    assert B.word_num(B.ALGO_MYERS, 1000, 1000) == 32
+    assert B.word_num(B.ALGO_MYERS, 1, 32) == 1 and B.word_num(B.ALGO_MYERS, 1, 33) == 2
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 4
+    assert B.group_words(B.ALGO_MYERS, 5) == 5 * 5 * 64
+    assert B.group_words(B.ALGO_BANDED, 4) == 2 * 5 * 4 * 64
+
+
+def test_mapping_table(L):
+    L.init_mapping_table()
+    table = (ctypes.c_uint32 * 128).in_dll(L, "mapping_table")
+    assert [table[ord(c)] for c in "ACGTN"] == [0, 1, 2, 3, 4]
+    assert table[ord("a")] == 0 and table[ord("X")] == 0 and table[ord("\n")] == 0
+
+
+def _host_preprocess(L, algo, rows, k=0, qlen=None):
+    rows, _ = B.pad_rows(rows)
+    n, length = rows.shape
+    buf = B.rows_to_buffer(rows)
+    wn = B.word_num(algo, length if qlen is None else qlen, length, k)
+    out = np.zeros(B.group_words(algo, wn) * (n // 64), dtype=np.uint32)
+    seq = B.SeqT(len=length, size=buf.size, count=n, extra_size=0, extra_count=0, content=buf.ctypes.data)
+    assert L.bgsa_hip_select_algorithm(algo) == 0
+    ctypes.c_int.in_dll(L, "threshold").value = k
+    ctypes.c_int.in_dll(L, "cpu_threads").value = 3
+    L.hip_handle_reads(ctypes.byref(seq), out.ctypes.data, wn, 0, n)
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    return rows, out, wn
+
+
+CODE = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+
+
+def test_host_handle_reads_layout_myers(L, oracle):
+    rows = oracle.gen_reads(77, 100, 150)
+    rows[3, 10:20] = ord("N")
+    rows, peq, wn = _host_preprocess(L, B.ALGO_MYERS, rows)
+    peq = peq.reshape(-1, 5, wn, 64)  # [group][char][word][lane]
+    for s in (0, 3, 63, 64, 99, 127):
+        g, lane = divmod(s, 64)
+        for p in range(150):
+            c = CODE[rows[s, p]]
+            for cc in range(5):
+                bit = (int(peq[g, cc, p // 32, lane]) >> (p % 32)) & 1
+                assert bit == (cc == c)
+    # every column is claimed by exactly one plane; nothing beyond the read
+    assert int(np.bitwise_count(peq).sum()) == 128 * 150
+
+
+def test_host_handle_reads_layout_banded(L, oracle):
+    rows = oracle.gen_reads(78, 64, 150)
+    k = 8
+    rows, peq, wn = _host_preprocess(L, B.ALGO_BANDED, rows, k=k)
+    assert wn == 4
+    peq = peq.view(np.uint64).reshape(-1, 5, wn, 64)
+    s = 5
+    for p in range(k):  # word 0: first k characters at bits k+1 .. 2k
+        assert (int(peq[0, CODE[rows[s, p]], 0, s]) >> (k + 1 + p)) & 1
+    for i in range(150 - k):  # words 1..: characters from index k, 64 per word
+        assert (int(peq[0, CODE[rows[s, k + i]], 1 + i // 64, s]) >> (i % 64)) & 1

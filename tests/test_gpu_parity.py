@@ -1,0 +1,89 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Bit-exact: every score is an integer.  Run with `pytest -m gpu` on an MI355X.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import bgsa_amd as B
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+ALGO_OF = {"original_cpu": B.ALGO_MYERS, "original_avx2": B.ALGO_BITPAL, "banded_cpu": B.ALGO_BANDED}
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixture(name):
+    g = load_golden(name)
+    algo = ALGO_OF[g["variant"]]
+    got = B.align_all_pairs(g["queries"], g["subjects"], algo=algo, k=max(g["k"], 0))
+    assert got.dtype == g["scores"].dtype
+    assert np.array_equal(got, g["scores"])
+
+
+@pytest.mark.parametrize("slen", [1, 7, 32, 33, 64, 100, 150, 151, 192, 250, 256, 300, 384, 448, 500, 640, 700, 800, 1000, 1024])
+def test_myers_lengths_vs_oracle(oracle, slen):
+    qlen = max(1, slen - 3)
+    q = oracle.gen_reads(1000 + slen, 5, qlen)
+    s = oracle.gen_reads(2000 + slen, 70, slen)
+    m = min(qlen, slen)
+    s[:20, :m] = oracle.mutate(q[np.arange(20) % 5][:, :m], np.arange(20) % 7, slen)
+    got = B.align_all_pairs(q, s, algo=B.ALGO_MYERS)
+    assert np.array_equal(got, oracle.myers64(q, s))
+
+
+def test_myers_query_tiles_and_offsets(oracle):
+    # ref_start/ref_end windows and many queries (several q-tiles), odd row alignment (stride 151)
+    q = oracle.gen_reads(31, 203, 150)
+    s = oracle.gen_reads(32, 256, 150)
+    want = oracle.myers64(q, s)
+    a = B.DeviceAligner(B.ALGO_MYERS)
+    a.set_queries(q)
+    a.set_subjects(s)
+    assert np.array_equal(a.score().cpu().numpy(), want)
+    assert np.array_equal(a.score(100, 203).cpu().numpy(), want[100:203])
+    assert np.array_equal(a.score(7, 8).cpu().numpy(), want[7:8])
+
+
+def test_bad_arguments_fail_loudly():
+    L = B.lib()
+    assert L.bgsa_hip_cal_align_score_dev(B.ALGO_MYERS, None, None, None, 150, 150, 64, 0, 1, 5, 0, None) == -1
+    assert b"bad argument" in L.bgsa_hip_last_error()
+
+
+def test_host_surface_matches_device_surface(oracle):
+    """hip_handle_reads + hip_cal_align_score + align_hip on HOST buffers (the reference's seams)."""
+    L = B.lib()
+    q = oracle.gen_reads(41, 9, 150)
+    s, _ = B.pad_rows(oracle.gen_reads(42, 130, 150))
+    want = oracle.myers64(q, s)
+    n, length = s.shape
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.init_mapping_table()
+    table = np.ctypeslib.as_array((ctypes.c_uint32 * 128).in_dll(L, "mapping_table"))
+    sbuf = B.rows_to_buffer(s)
+    seq = B.SeqT(len=length, size=sbuf.size, count=n, extra_size=0, extra_count=0, content=sbuf.ctypes.data)
+    wn = B.word_num(B.ALGO_MYERS, 150, length)
+    peq = np.zeros(B.group_words(B.ALGO_MYERS, wn) * (n // 64), dtype=np.uint32)
+    L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+    # queries mapped through mapping_table the way get_ref_from_file does (file.c:134-139)
+    qbuf = B.rows_to_buffer(q)
+    keep = qbuf == ord("\n")
+    qmapped = table[qbuf].astype(np.uint8)
+    qmapped[keep] = ord("\n")
+    out = np.zeros((9, n), dtype=np.int16)
+    L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, 150, 9, length, n, 0, 9, wn, 27, None)
+    assert np.array_equal(out, want)
+    # a ref window
+    out2 = np.zeros((4, n), dtype=np.int16)
+    L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out2.ctypes.data, 150, 9, length, n, 3, 7, wn, 27, None)
+    assert np.array_equal(out2, want[3:7])
+    # fine-grained README-style call: one query against the second group only
+    res = np.zeros(n, dtype=np.int16)
+    row = np.ascontiguousarray(qmapped[2 * 151: 3 * 151])
+    group1 = peq[B.group_words(B.ALGO_MYERS, wn):]
+    L.align_hip(row.ctypes.data, group1.ctypes.data, 150, length, wn, 1, 1, res.ctypes.data, None)
+    assert np.array_equal(res[64:128], want[2, 64:128]) and not res[:64].any()
