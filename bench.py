@@ -103,7 +103,7 @@ def main() -> int:
     ap.add_argument("--nq", type=int, default=None, help="override query count (not the BASELINE config)")
     ap.add_argument("--ns", type=int, default=None, help="override subjects per GPU (not the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=str, default="1000x20000", help="queries x subjects timed on the CPU")
+    ap.add_argument("--cpu-sample", type=str, default="2000x100000", help="queries x subjects timed on the CPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
