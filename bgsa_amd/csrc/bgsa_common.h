@@ -29,8 +29,18 @@ void set_error_text(const char *text);
 // Launchers implemented in the per-algorithm .hip files.  All pointers are device pointers.
 int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                 hipStream_t stream);
+                 void *d_workspace, hipStream_t stream);
 const char *myers_kernel_name(int word_num);
+
+// Packed query stream (one per query, 8-byte windows): codes 0..4 = A C G T N row, 5 = END,
+// 6 = REFILL.  Window i < n_windows-1 holds characters 7i..7i+6 and a REFILL; the last window
+// holds the remaining characters, an END, and END padding; one spare all-END window follows
+// (the kernels fetch one window ahead).
+constexpr int kCodeEnd = 5, kCodeRefill = 6;
+inline int stream_windows(int ref_len) { return ref_len / 7 + 1; }
+inline size_t stream_stride(int ref_len) { return static_cast<size_t>(stream_windows(ref_len) + 1) * 8; }
+int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
+                        void *d_streams, hipStream_t stream);
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, int k,

@@ -33,8 +33,8 @@ static int g_algo = BGSA_ALGO_MYERS;
 
 // Grow-only device workspace behind the host-buffer entry points.
 struct HostPathWorkspace {
-    void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr;
-    size_t cap_content = 0, cap_peq = 0, cap_results = 0;
+    void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr, *d_scratch = nullptr;
+    size_t cap_content = 0, cap_peq = 0, cap_results = 0, cap_scratch = 0;
     int reserve(void **p, size_t *cap, size_t need)
     {
         if (need <= *cap) return BGSA_HIP_OK;
@@ -201,9 +201,17 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream)
     return launch_map_queries(d_content, bytes, static_cast<hipStream_t>(stream));
 }
 
+size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int n_queries)
+{
+    (void)algo;
+    if (ref_len <= 0 || n_queries <= 0) return 0;
+    return stream_stride(ref_len) * static_cast<size_t>(n_queries);
+}
+
 int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read_t *d_peq,
                                  void *d_results, int ref_len, int read_len, int64_t read_count,
-                                 int ref_start, int ref_end, int word_num, int k, void *stream)
+                                 int ref_start, int ref_end, int word_num, int k,
+                                 void *d_workspace, size_t workspace_bytes, void *stream)
 {
     if (!d_content || !d_peq || !d_results || ref_len <= 0 || read_len <= 0 || read_count < 0 ||
         (read_count % HIP_V_NUM) != 0 || ref_start < 0 || ref_end < ref_start || word_num <= 0) {
@@ -211,6 +219,16 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         return BGSA_HIP_EINVAL;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t need = bgsa_hip_workspace_bytes(algo, ref_len, ref_end - ref_start);
+    if (d_workspace) {
+        if (workspace_bytes < need) {
+            set_error_text("cal_align_score_dev: workspace smaller than bgsa_hip_workspace_bytes()");
+            return BGSA_HIP_EINVAL;
+        }
+    } else {
+        if (g_ws.reserve(&g_ws.d_scratch, &g_ws.cap_scratch, need)) return BGSA_HIP_EHIP;
+        d_workspace = g_ws.d_scratch;
+    }
     switch (algo) {
     case BGSA_ALGO_MYERS:
         if (word_num != (read_len + 31) / 32) {
@@ -218,7 +236,7 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
             return BGSA_HIP_EINVAL;
         }
         return launch_myers(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len, read_len,
-                            read_count, ref_start, ref_end, word_num, s);
+                            read_count, ref_start, ref_end, word_num, d_workspace, s);
     case BGSA_ALGO_BANDED:
         return launch_banded(d_content, d_peq, static_cast<int8_t *>(d_results), ref_len, read_len,
                              read_count, ref_start, ref_end, word_num, k, s);
@@ -280,7 +298,7 @@ void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_
     if (bgsa_hip_cal_align_score_dev(g_algo, static_cast<const char *>(g_ws.d_content),
                                      static_cast<const hip_read_t *>(g_ws.d_peq), g_ws.d_results,
                                      ref_len, read_len, read_count, ref_start, ref_end, word_num,
-                                     threshold, nullptr) != BGSA_HIP_OK)
+                                     threshold, nullptr, 0, nullptr) != BGSA_HIP_OK)
         die("hip_cal_align_score");
     hipError_t e = hipMemcpy(align_results, g_ws.d_results, res_bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) {

@@ -20,19 +20,24 @@
 //   v_alignbit) against the reference's 24.
 //
 // Integer/bitwise only; no LDS, no MFMA.  The kernel is VALU-issue bound.
+#include <stdlib.h>
+
 #include "bgsa_common.h"
 
 namespace bgsa {
 
 // One DP row: in-place update of the vertical delta vectors for query character class `eq`.
-template <int NW>
-__device__ __forceinline__ void myers_row(uint32_t (&vp)[NW], uint32_t (&vn)[NW],
-                                          const uint32_t (&eq)[NW])
+template <int NW, int G>
+__device__ __forceinline__ void myers_row(uint32_t (&vp)[G * NW], uint32_t (&vn)[G * NW],
+                                          const uint32_t (&eq)[G * NW])
 {
+#pragma unroll
+  for (int gi = 0; gi < G; gi++) {
     uint32_t hp_prev = 0, hn_prev = 0;
     unsigned carry = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
+    for (int ww = 0; ww < NW; ww++) {
+        const int w = gi * NW + ww;
         const uint32_t pv = vp[w], mv = vn[w], e = eq[w];
         const uint32_t pm = e | mv;
         // (pv & pm) == (pv & e) because pv & mv == 0 is an invariant of the recurrence.
@@ -43,43 +48,51 @@ __device__ __forceinline__ void myers_row(uint32_t (&vp)[NW], uint32_t (&vn)[NW]
         const uint32_t hp = ~(d0 | pv) | mv;
         const uint32_t hn = d0 & pv;
         // Shift one column along the subject; row boundary D[i][0]-D[i-1][0] = +1 enters word 0.
-        const uint32_t hps = (w == 0) ? ((hp << 1) | 1u) : ((hp << 1) | (hp_prev >> 31));
-        const uint32_t hns = (w == 0) ? (hn << 1) : ((hn << 1) | (hn_prev >> 31));
+        const uint32_t hps = (ww == 0) ? ((hp << 1) | 1u) : ((hp << 1) | (hp_prev >> 31));
+        const uint32_t hns = (ww == 0) ? (hn << 1) : ((hn << 1) | (hn_prev >> 31));
         hp_prev = hp;
         hn_prev = hn;
         vp[w] = ~(d0 | hps) | hns;
         vn[w] = d0 & hps;
     }
+  }
 }
 
-// grid.x = ceil(n_groups / 4), grid.y = number of query tiles; block = 4 waves = 4 groups.
-template <int NW>
+// grid.x = ceil(n_groups / (4*G)), grid.y = number of query tiles; block = 4 waves, each wave
+// owns G consecutive groups (G subjects per lane): the scalar work of a row (character fetch,
+// 5-way branch) is shared by G x NW word updates.
+template <int NW, int G>
 __global__ __launch_bounds__(256) void myers_global_kernel(
     const char *__restrict__ content, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     int ref_len, int read_len, long long ld, int n_groups, int word_num, int ref_start,
     int ref_end, int q_tile)
 {
     const int lane = threadIdx.x & (kLanes - 1);
-    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (group >= n_groups) return;
+    const int group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
+    if (group0 >= n_groups) return;
 
-    // Peq block of this group: [char][word][lane], coalesced 256-B rows.
-    uint32_t P[kChars][NW];
-    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+    // Peq blocks of this wave's groups: [char][word][lane], coalesced 256-B rows.  A group past
+    // the end of the bucket is computed on zero masks and not stored.
+    uint32_t P[kChars][G * NW];
 #pragma unroll
-    for (int c = 0; c < kChars; c++)
+    for (int gi = 0; gi < G; gi++) {
+        const bool live = group0 + gi < n_groups;
+        const uint32_t *g = peq + static_cast<size_t>(group0 + gi) * kChars * word_num * kLanes + lane;
 #pragma unroll
-        for (int w = 0; w < NW; w++)
-            P[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+        for (int c = 0; c < kChars; c++)
+#pragma unroll
+            for (int w = 0; w < NW; w++)
+                P[c][gi * NW + w] = (live && w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+    }
 
     const int q0 = ref_start + blockIdx.y * q_tile;
     const int q1 = (q0 + q_tile < ref_end) ? q0 + q_tile : ref_end;
-    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+    int16_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
 
     for (int q = q0; q < q1; q++) {
-        uint32_t vp[NW], vn[NW];
+        uint32_t vp[G * NW], vn[G * NW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
+        for (int w = 0; w < G * NW; w++) {
             vp[w] = ~0u;
             vn[w] = 0u;
         }
@@ -88,22 +101,87 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
             if ((r & 3) == 0) qs.refill(r, ref_len - r);
             const uint32_t c = __builtin_amdgcn_readfirstlane(qs.next());
             switch (c) {
-            case 0: myers_row<NW>(vp, vn, P[0]); break;
-            case 1: myers_row<NW>(vp, vn, P[1]); break;
-            case 2: myers_row<NW>(vp, vn, P[2]); break;
-            case 3: myers_row<NW>(vp, vn, P[3]); break;
-            default: myers_row<NW>(vp, vn, P[4]); break;
+            case 0: myers_row<NW, G>(vp, vn, P[0]); break;
+            case 1: myers_row<NW, G>(vp, vn, P[1]); break;
+            case 2: myers_row<NW, G>(vp, vn, P[2]); break;
+            case 3: myers_row<NW, G>(vp, vn, P[3]); break;
+            default: myers_row<NW, G>(vp, vn, P[4]); break;
             }
         }
         // D[m][n] = m + sum over the n subject columns of (VP - VN).
-        int score = ref_len;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const int rem = read_len - 32 * w;
-            const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-            score += __popc(vp[w] & m) - __popc(vn[w] & m);
+        for (int gi = 0; gi < G; gi++) {
+            int score = ref_len;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int rem = read_len - 32 * w;
+                const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                score += __popc(vp[gi * NW + w] & m) - __popc(vn[gi * NW + w] & m);
+            }
+            if (group0 + gi < n_groups)
+                dst[static_cast<size_t>(q - ref_start) * ld + gi * kLanes] = static_cast<int16_t>(-score);
         }
-        dst[static_cast<size_t>(q - ref_start) * ld] = static_cast<int16_t>(-score);
+    }
+}
+
+// ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
+#include "myers_rows_gen.inc"
+
+// Same task decomposition as above, but all rows of a query run inside one generated asm block:
+// five in-place row bodies selected by a scalar jump per row, every VALU instruction full rate
+// (the inter-word shifts are add-with-carry chains instead of v_alignbit_b32), query characters
+// from the packed code stream.  This is the kernel the launcher picks whenever NW <= 8.
+template <int NW, int G>
+__global__ __launch_bounds__(256) void myers_global_asm_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
+    int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
+    if (group0 >= n_groups) return;
+
+    uint32_t P[kChars][G * NW];
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        const bool live = group0 + gi < n_groups;
+        const uint32_t *g = peq + static_cast<size_t>(group0 + gi) * kChars * word_num * kLanes + lane;
+#pragma unroll
+        for (int c = 0; c < kChars; c++)
+#pragma unroll
+            for (int w = 0; w < NW; w++)
+                P[c][gi * NW + w] = (live && w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+    }
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int16_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        uint32_t vp[G * NW], vn[G * NW];
+#pragma unroll
+        for (int w = 0; w < G * NW; w++) {
+            vp[w] = ~0u;
+            vn[w] = 0u;
+        }
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        myers_rows_asm<NW, G>(vp, vn, P, __builtin_amdgcn_readfirstlane(static_cast<unsigned>(s)) |
+                                             (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(
+                                                  static_cast<unsigned>(s >> 32)))
+                                              << 32));
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+            int score = ref_len;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int rem = read_len - 32 * w;
+                const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                score += __popc(vp[gi * NW + w] & m) - __popc(vn[gi * NW + w] & m);
+            }
+            if (group0 + gi < n_groups)
+                dst[static_cast<size_t>(q) * ld + gi * kLanes] = static_cast<int16_t>(-score);
+        }
     }
 }
 
@@ -130,7 +208,40 @@ int pick_q_tile(int nq, int64_t n_groups)
     return q_tile;
 }
 
-template <int NW>
+// 0 = generated-asm row loop (default), 1 = compiler-scheduled C++ kernel (A/B and NW > 8).
+int myers_impl()
+{
+    static const int impl = [] {
+        const char *e = getenv("BGSA_MYERS_IMPL");
+        return (e && e[0] == 'c') ? 1 : 0;
+    }();
+    return impl;
+}
+
+template <int NW, int G>
+int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+               int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+               void *d_workspace, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    const int q_tile = pick_q_tile(nq, n_groups);
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("myers: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    hipLaunchKernelGGL((myers_global_asm_kernel<NW, G>), grid, dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                       read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)));
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+template <int NW, int G>
 int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
               int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
               hipStream_t stream)
@@ -138,13 +249,13 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     const int q_tile = pick_q_tile(nq, n_groups);
-    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
         set_error_text("myers: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(myers_global_kernel<NW>, grid, dim3(256), 0, stream, d_content, d_peq,
+    hipLaunchKernelGGL((myers_global_kernel<NW, G>), grid, dim3(256), 0, stream, d_content, d_peq,
                        d_results, ref_len, read_len, static_cast<long long>(read_count),
                        static_cast<int>(n_groups), word_num, ref_start, ref_end, q_tile);
     BGSA_HIP_TRY(hipGetLastError());
@@ -158,19 +269,31 @@ const char *myers_kernel_name(int word_num)
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
     if (nw < 0) return "myers_global_kernel<unsupported>";
-    snprintf(name, sizeof name, "myers_global_kernel<%d>", nw);
+    snprintf(name, sizeof name, "%s<%d, 1>", (nw <= 8 && myers_impl() == 0) ? "myers_global_asm_kernel" : "myers_global_kernel", nw);
     return name;
 }
 
 int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                 hipStream_t stream)
+                 void *d_workspace, hipStream_t stream)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
+    if (myers_impl() == 0) {
+        switch (pick_nw(word_num)) {
+#define BGSA_ASM_CASE(N)                                                                        \
+    case N:                                                                                     \
+        return launch_asm<N, 1>(d_content, d_peq, d_results, ref_len, read_len, read_count,     \
+                                ref_start, ref_end, word_num, d_workspace, stream);
+            BGSA_ASM_CASE(1) BGSA_ASM_CASE(2) BGSA_ASM_CASE(3) BGSA_ASM_CASE(4) BGSA_ASM_CASE(5)
+            BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8)
+#undef BGSA_ASM_CASE
+        default: break;
+        }
+    }
     switch (pick_nw(word_num)) {
 #define BGSA_CASE(N)                                                                            \
     case N:                                                                                     \
-        return launch_nw<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,         \
+        return launch_nw<N, 1>(d_content, d_peq, d_results, ref_len, read_len, read_count,         \
                             ref_start, ref_end, word_num, stream);
         BGSA_CASE(1) BGSA_CASE(2) BGSA_CASE(3) BGSA_CASE(4) BGSA_CASE(5) BGSA_CASE(6)
         BGSA_CASE(7) BGSA_CASE(8) BGSA_CASE(10) BGSA_CASE(12) BGSA_CASE(14) BGSA_CASE(16)

@@ -106,6 +106,49 @@ __global__ __launch_bounds__(256) void map_queries_kernel(char *content, long lo
     if (ch != '\n') content[i] = static_cast<char>(map_char(ch));
 }
 
+// ---- query packer -----------------------------------------------------------------------------------
+// mapped query rows (codes 0..4, stride ref_len+1) -> code streams of 8-byte windows
+// (bgsa_common.h "Packed query stream").  One thread per (query, window).
+__global__ __launch_bounds__(256) void pack_queries_kernel(const char *__restrict__ content,
+                                                           unsigned long long *__restrict__ streams,
+                                                           int ref_len, int ref_start, int n_queries,
+                                                           int n_windows)
+{
+    const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int per = n_windows + 1;  // + the spare all-END window
+    if (tid >= static_cast<long long>(n_queries) * per) return;
+    const int q = static_cast<int>(tid / per), i = static_cast<int>(tid % per);
+    const char *row = content + static_cast<size_t>(ref_start + q) * (ref_len + 1);
+    unsigned long long win = 0;
+    for (int j = 0; j < 8; j++) {
+        unsigned code = kCodeEnd;
+        if (i < n_windows) {
+            const int pos = 7 * i + j;
+            if (j == 7) code = (i < n_windows - 1) ? kCodeRefill : kCodeEnd;
+            else if (pos < ref_len) {
+                code = static_cast<uint8_t>(row[pos]);
+                if (code > 4) code = 0;  // the reference would index Peq out of range; treat as 'A'
+            }
+        }
+        win |= static_cast<unsigned long long>(code) << (8 * j);
+    }
+    streams[tid] = win;
+}
+
+int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
+                        void *d_streams, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    if (nq <= 0) return BGSA_HIP_OK;
+    const int n_windows = stream_windows(ref_len);
+    const long long total = static_cast<long long>(nq) * (n_windows + 1);
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       stream, d_content, static_cast<unsigned long long *>(d_streams), ref_len, ref_start,
+                       nq, n_windows);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
 int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
                       int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream)
 {

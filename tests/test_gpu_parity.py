@@ -50,7 +50,7 @@ def test_myers_query_tiles_and_offsets(oracle):
 
 def test_bad_arguments_fail_loudly():
     L = B.lib()
-    assert L.bgsa_hip_cal_align_score_dev(B.ALGO_MYERS, None, None, None, 150, 150, 64, 0, 1, 5, 0, None) == -1
+    assert L.bgsa_hip_cal_align_score_dev(B.ALGO_MYERS, None, None, None, 150, 150, 64, 0, 1, 5, 0, None, 0, None) == -1
     assert b"bad argument" in L.bgsa_hip_last_error()
 
 
