@@ -49,7 +49,7 @@ const char *banded_kernel_name(int word_num);
 
 int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                  hipStream_t stream);
+                  void *d_workspace, hipStream_t stream);
 const char *bitpal_kernel_name(int word_num);
 
 int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
@@ -90,5 +90,13 @@ struct UniformBytes {
         return c;
     }
 };
+
+// A 64-bit value the compiler cannot prove wave-uniform, forced into an SGPR pair.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
 
 }  // namespace bgsa

@@ -101,7 +101,7 @@ int bgsa_hip_select_algorithm(int algo)
         break;
     case BGSA_ALGO_BITPAL:
         match_score = 2; mismatch_score = -3; gap_score = -5;  // original/BGSA_AVX2/align_core.c:13-15
-        full_bits = 0;
+        full_bits = 1;
         break;
     default:
         set_error_text("unknown algorithm");
@@ -117,7 +117,7 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k)
 {
     switch (algo) {
     case BGSA_ALGO_MYERS: return (subject_len + 31) / 32;   // cal_cpu.c:252-253, full_bits
-    case BGSA_ALGO_BITPAL: return (subject_len + 30) / 31;  // cal_cpu.c:255, 31 data bits
+    case BGSA_ALGO_BITPAL: return (subject_len + 31) / 32;  // same layout as Myers
     case BGSA_ALGO_BANDED: {
         const int h = k + subject_len - query_len;           // banded cal_cpu.c:253-254
         return (subject_len - h + 63) / 64 + 1;
@@ -241,8 +241,12 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         return launch_banded(d_content, d_peq, static_cast<int8_t *>(d_results), ref_len, read_len,
                              read_count, ref_start, ref_end, word_num, k, s);
     case BGSA_ALGO_BITPAL:
+        if (word_num != (read_len + 31) / 32) {
+            set_error_text("cal_align_score_dev: word_num does not match read_len for BitPAl");
+            return BGSA_HIP_EINVAL;
+        }
         return launch_bitpal(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len,
-                             read_len, read_count, ref_start, ref_end, word_num, s);
+                             read_len, read_count, ref_start, ref_end, word_num, d_workspace, s);
     default:
         set_error_text("cal_align_score_dev: unknown algorithm");
         return BGSA_HIP_EINVAL;

@@ -158,26 +158,23 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     int16_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
 
     for (int q = q0; q < q1; q++) {
-        uint32_t vp[G * NW], vn[G * NW];
+        uint32_t st[2 * G * NW];  // {VP, VN} per word
 #pragma unroll
         for (int w = 0; w < G * NW; w++) {
-            vp[w] = ~0u;
-            vn[w] = 0u;
+            st[2 * w] = ~0u;
+            st[2 * w + 1] = 0u;
         }
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        myers_rows_asm<NW, G>(vp, vn, P, __builtin_amdgcn_readfirstlane(static_cast<unsigned>(s)) |
-                                             (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(
-                                                  static_cast<unsigned>(s >> 32)))
-                                              << 32));
+        myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
-            int score = ref_len;
+            int score = ref_len;  // D[m][n] = m + sum over the n subject columns of (VP - VN)
 #pragma unroll
             for (int w = 0; w < NW; w++) {
                 const int rem = read_len - 32 * w;
                 const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-                score += __popc(vp[gi * NW + w] & m) - __popc(vn[gi * NW + w] & m);
+                score += __popc(st[2 * (gi * NW + w)] & m) - __popc(st[2 * (gi * NW + w) + 1] & m);
             }
             if (group0 + gi < n_groups)
                 dst[static_cast<size_t>(q) * ld + gi * kLanes] = static_cast<int16_t>(-score);

@@ -8,7 +8,7 @@
 // Layout produced, for every group of 64 consecutive subjects:
 //     peq[group][char 0..4][word 0..word_num-1][lane 0..63]
 // Global Myers / BitPAl: 32-bit words, bit (p mod D) of word (p div D) set iff subject[p] maps to
-// `char`, D = data bits per word (32 for Myers, 31 or 32 for BitPAl — see bitpal.hip).
+// `char`, D = 32 data bits per word (the reference keeps one bit per word as a software carry).
 // Banded: 64-bit words; word 0 = first k characters at bits k+1..2k, words 1.. = characters
 // k, k+1, ... 64 per word (banded/BGSA_CPU/global.c:44-82).
 #include <algorithm>
@@ -160,8 +160,7 @@ int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len
                            len, static_cast<long long>(read_count), word_num, k);
     } else {
         hipLaunchKernelGGL(preprocess_global_kernel, dim3(blocks), dim3(256), 0, stream, d_rows,
-                           d_peq, len, static_cast<long long>(read_count), word_num,
-                           algo == BGSA_ALGO_BITPAL ? 31 : 32);
+                           d_peq, len, static_cast<long long>(read_count), word_num, 32);
     }
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
@@ -206,7 +205,7 @@ void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint3
                         dst[(map_char(ch) * word_num + w) * kLanes] |= 1ULL << (i % 64);
                     }
                 } else {
-                    const int bits = algo == BGSA_ALGO_BITPAL ? 31 : 32;
+                    const int bits = 32;
                     uint32_t *dst = result_reads + static_cast<size_t>(g) * kChars * word_num * kLanes + lane;
                     for (int p = 0; p < len; p++) {
                         const uint32_t c = map_char(static_cast<uint8_t>(row[p]));

@@ -1,0 +1,407 @@
+#!/usr/bin/env python3
+"""rows_ir.py — the DP row bodies of the gfx950 kernels as a tiny instruction-level IR.
+
+One description of each algorithm's row update serves two consumers:
+
+  * emit_asm():  gfx950 assembly text for the inline-asm row loops (gen_rows_asm.py), and
+  * simulate():  a numpy interpreter of the very same instruction list, so the instruction
+                 stream that ships can be checked bit-for-bit against the oracle on a CPU
+                 (tests/test_rows_ir.py) before it ever runs on a GPU.
+
+BGSA's reference emits its kernels from a generator as well (generator/source/src/main/java/org/
+sduhpcl/bgsa/generator/{MyersGenerator,BitPAlGenerator}.java); this is the gfx950 counterpart.
+
+Instruction selection follows scripts/ubench/valu_rate.hip, measured on MI355X:
+  fast class (~2.2 cycles per wave64 instruction): v_and/v_or/v_xor/v_not/v_mov/v_add_u32,
+      v_bitop3_b32 (any 3-input boolean), and the 4-byte VOP2 forms of v_add_co/v_addc_co that
+      carry through VCC;
+  slow class (~4.2 cycles, and they drag neighbouring fast instructions down with them):
+      v_lshlrev/v_lshrrev, v_alignbit, v_lshl_or, v_and_or, v_or3, v_bfi, v_add3, v_bcnt, v_cmp and
+      every VOP3 form that reads or writes an SGPR-pair carry.
+So every 1-bit shift across words is an add-with-carry chain (x + x + carry), every chain goes
+through VCC, and chains are serialised into phases.  gfx950 hazard "VALU writes VCC -> VALU reads
+VCC as carry-in: 2 wait states" is enforced by the emitter (it counts the instructions between the
+links of a chain and pads with s_nop if an ordering ever leaves fewer than two).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def tt(fn) -> int:
+    """Truth table immediate of v_bitop3_b32 for a boolean function of (a, b, c)."""
+    return fn(0xF0, 0xCC, 0xAA) & 0xFF
+
+
+TT_XOR3 = tt(lambda a, b, c: a ^ b ^ c)
+TT_MAJ = tt(lambda a, b, c: (a & b) | (a & c) | (b & c))
+TT_OR3 = tt(lambda a, b, c: a | b | c)
+TT_NOR3 = tt(lambda a, b, c: ~(a | b | c))
+
+
+@dataclass
+class Op:
+    kind: str                 # and or xor not mov bitop3 add_co addc setc1
+    dst: str = ""
+    srcs: tuple = ()
+    imm: int = 0
+
+
+@dataclass
+class Body:
+    """Straight-line row body.  Register names: 'S<i>' persistent state (updated in place),
+    'E<j>' the match masks of the current query character, anything else is a temporary."""
+    ops: list = field(default_factory=list)
+
+    def _emit(self, kind, dst, *srcs, imm=0):
+        self.ops.append(Op(kind, dst, tuple(srcs), imm))
+        return dst
+
+    def AND(self, d, a, b): return self._emit("and", d, a, b)
+    def OR(self, d, a, b): return self._emit("or", d, a, b)
+    def XOR(self, d, a, b): return self._emit("xor", d, a, b)
+    def NOT(self, d, a): return self._emit("not", d, a)
+    def MOV(self, d, a): return self._emit("mov", d, a)
+    def BITOP3(self, d, a, b, c, fn): return self._emit("bitop3", d, a, b, c, imm=tt(fn))
+    def ADD_CO(self, d, a, b): return self._emit("add_co", d, a, b)   # d = a + b, VCC = carry out
+    def ADDC(self, d, a, b): return self._emit("addc", d, a, b)       # d = a + b + VCC, VCC = carry out
+    def SETC1(self): return self._emit("setc1", "")                    # VCC = all ones (carry-in 1)
+
+    # ---- analysis ---------------------------------------------------------------------------
+    def temps(self) -> list[str]:
+        seen = []
+        for op in self.ops:
+            for r in (op.dst,) + op.srcs:
+                if r and not r.startswith(("S", "E")) and r not in seen:
+                    seen.append(r)
+        return seen
+
+    def allocate_temps(self) -> tuple[dict, int]:
+        """Linear-scan reuse of temporaries: name -> slot, and the number of slots needed."""
+        last_use = {}
+        for i, op in enumerate(self.ops):
+            for r in (op.dst,) + op.srcs:
+                if r and not r.startswith(("S", "E")):
+                    last_use[r] = i
+        slot_of, free, n_slots = {}, [], 0
+        for i, op in enumerate(self.ops):
+            # sources die at their last use, before the destination of this op is placed only if
+            # the hardware reads operands before writing (it does: dst may alias a dying source)
+            dying = sorted({r for r in op.srcs if r in slot_of and last_use[r] == i and r != op.dst})
+            for r in dying:
+                free.append(slot_of[r])
+            d = op.dst
+            if d and not d.startswith(("S", "E")) and d not in slot_of:
+                if free:
+                    slot_of[d] = free.pop()
+                else:
+                    slot_of[d] = n_slots
+                    n_slots += 1
+            if d and d in slot_of and last_use.get(d, -1) == i:  # written, never read
+                free.append(slot_of[d])
+        return slot_of, n_slots
+
+    def valu_count(self) -> int:
+        return sum(op.kind != "setc1" for op in self.ops)
+
+    # ---- numpy interpreter --------------------------------------------------------------------
+    def simulate(self, state: list, eq: list) -> None:
+        """state: list of uint32 arrays (updated in place); eq: list of uint32 arrays."""
+        regs: dict[str, np.ndarray] = {}
+        vcc = np.zeros_like(state[0], dtype=bool)
+
+        def rd(name):
+            if name.startswith("S"):
+                return state[int(name[1:])]
+            if name.startswith("E"):
+                return eq[int(name[1:])]
+            return regs[name]
+
+        def wr(name, val):
+            val = val.astype(np.uint32)
+            if name.startswith("S"):
+                state[int(name[1:])] = val
+            else:
+                regs[name] = val
+
+        FULL = np.uint32(0xFFFFFFFF)
+        for op in self.ops:
+            k = op.kind
+            if k == "setc1":
+                vcc = np.ones_like(vcc)
+                continue
+            s = [rd(x) for x in op.srcs]
+            if k == "and": wr(op.dst, s[0] & s[1])
+            elif k == "or": wr(op.dst, s[0] | s[1])
+            elif k == "xor": wr(op.dst, s[0] ^ s[1])
+            elif k == "not": wr(op.dst, s[0] ^ FULL)
+            elif k == "mov": wr(op.dst, s[0])
+            elif k == "bitop3":
+                a, b, c = s
+                out = np.zeros_like(a)
+                for idx in range(8):
+                    if (op.imm >> idx) & 1:
+                        ta = a if idx & 4 else a ^ FULL
+                        tb = b if idx & 2 else b ^ FULL
+                        tc = c if idx & 1 else c ^ FULL
+                        out |= ta & tb & tc
+                wr(op.dst, out)
+            elif k in ("add_co", "addc"):
+                wide = s[0].astype(np.uint64) + s[1].astype(np.uint64)
+                if k == "addc":
+                    wide = wide + vcc.astype(np.uint64)
+                vcc = (wide >> np.uint64(32)) != 0
+                wr(op.dst, wide & np.uint64(0xFFFFFFFF))
+            else:
+                raise ValueError(k)
+
+    # ---- gfx950 assembly ------------------------------------------------------------------------
+    def emit_asm(self, reg_name) -> list[str]:
+        """reg_name(name) -> asm operand text.  Returns instruction lines with hazard padding."""
+        lines: list[str] = []
+        since_vcc_write = 99  # instructions issued since the last write of VCC
+        for op in self.ops:
+            k = op.kind
+            if k == "setc1":
+                lines.append("s_mov_b64 vcc, -1")
+                since_vcc_write = 0
+                continue
+            r = [reg_name(x) for x in op.srcs]
+            d = reg_name(op.dst)
+            if k == "addc" and since_vcc_write < 2:
+                lines.append(f"s_nop {1 - since_vcc_write}")
+                since_vcc_write = 2
+            if k == "and": lines.append(f"v_and_b32 {d}, {r[0]}, {r[1]}")
+            elif k == "or": lines.append(f"v_or_b32 {d}, {r[0]}, {r[1]}")
+            elif k == "xor": lines.append(f"v_xor_b32 {d}, {r[0]}, {r[1]}")
+            elif k == "not": lines.append(f"v_not_b32 {d}, {r[0]}")
+            elif k == "mov": lines.append(f"v_mov_b32 {d}, {r[0]}")
+            elif k == "bitop3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm:02x}")
+            elif k == "add_co": lines.append(f"v_add_co_u32 {d}, vcc, {r[0]}, {r[1]}")
+            elif k == "addc": lines.append(f"v_addc_co_u32 {d}, vcc, {r[0]}, {r[1]}, vcc")
+            else:
+                raise ValueError(k)
+            since_vcc_write = 0 if k in ("add_co", "addc") else since_vcc_write + 1
+        return lines
+
+
+# =================================================================================================
+# Myers unit-cost global (reference original/BGSA_CPU/align_core.c:65-132)
+# =================================================================================================
+
+def myers_body(nw: int, groups: int = 1) -> Body:
+    """State layout: S[(g*nw + w)*2 + 0] = VP word w of group g, +1 = VN.  E[g*nw + w] = match mask.
+
+    Per word (10 instructions, full 32-bit words, hardware carries instead of the reference's
+    software carry bit, align_core.c:79-83,91-96):
+        D0 = (((P & E) + P) ^ P) | E | M ; HP = ~(D0 | P) | M ; HN = D0 & P
+        HP, HN <<= 1 (row boundary feeds 1 into HP)  ; P' = ~(D0 | HP) | HN ; M' = D0 & HP
+    """
+    b = Body()
+    for g in range(groups):
+        P = lambda w: f"S{(g * nw + w) * 2}"
+        M = lambda w: f"S{(g * nw + w) * 2 + 1}"
+        E = lambda w: f"E{g * nw + w}"
+        D = lambda w: f"d{g}_{w}"
+        HP = lambda w: f"hp{g}_{w}"
+        HN = lambda w: f"hn{g}_{w}"
+        for w in range(nw):  # phase A: the addition's carry chain
+            b.AND(D(w), P(w), E(w))   # (P & (E|M)) == (P & E): P & M == 0 is an invariant
+            (b.ADD_CO if w == 0 else b.ADDC)(D(w), D(w), P(w))
+            b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
+            b.OR(D(w), D(w), E(w))
+        b.SETC1()  # D[i][0] - D[i-1][0] = +1 enters HP at bit 0 of word 0
+        for w in range(nw):  # phase C: HP << 1 across words
+            b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
+            b.AND(HN(w), D(w), P(w))
+            b.ADDC(HP(w), HP(w), HP(w))
+        for w in range(nw):  # phase D: HN << 1 across words, then the new vertical deltas
+            (b.ADD_CO if w == 0 else b.ADDC)(HN(w), HN(w), HN(w))
+            b.AND(M(w), D(w), HP(w))
+            b.BITOP3(P(w), D(w), HP(w), HN(w), lambda d, hp, hn: ~(d | hp) | hn)
+    return b
+
+
+def myers_init_state(nw: int, groups: int, lanes: int) -> list:
+    st = []
+    for _ in range(groups * nw):
+        st += [np.full(lanes, 0xFFFFFFFF, dtype=np.uint32), np.zeros(lanes, dtype=np.uint32)]
+    return st
+
+
+def myers_score(state: list, nw: int, qlen: int, slen: int, group: int = 0) -> np.ndarray:
+    score = np.full(state[0].shape, qlen, dtype=np.int64)
+    for w in range(nw):
+        rem = slen - 32 * w
+        mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
+        score += np.bitwise_count(state[(group * nw + w) * 2] & mask).astype(np.int64)
+        score -= np.bitwise_count(state[(group * nw + w) * 2 + 1] & mask).astype(np.int64)
+    return (-score).astype(np.int16)
+
+
+# =================================================================================================
+# BitPAl packed, match 2 / mismatch -3 / gap -5 (reference original/BGSA_AVX2/align_core.c:183-428)
+# =================================================================================================
+
+def bitpal_body(nw: int) -> Body:
+    """State layout: S[w*5 + i] = plane i (weights 1,2,4,8,16) of word w; E[w] = match mask.
+
+    The planes hold, per subject column, the 5-bit two's complement of -(dH + 5): 0 = dH -5 ...
+    0b11001 = dH +2 (align_core.c:191-214).  Words are full 32-bit here (the reference keeps bit 31
+    as a software carry): all fourteen inter-word carries of align_core.c:176-179 — five adds,
+    four seed shifts, the plane shifts — ride VCC chains, one chain per phase.
+    """
+    b = Body()
+    H = lambda w, i: f"S{w * 5 + i}"
+    E = lambda w: f"E{w}"
+    t = lambda name, w: f"{name}_{w}"
+    W = range(nw)
+
+    # ---- decode dH classes (:191-214) + phase 1: dV = +7 run propagation (:216-223) ----------
+    for w in W:
+        b.AND(t("top", w), H(w, 4), H(w, 3))
+        b.BITOP3(t("o3", w), H(w, 2), H(w, 1), H(w, 0), lambda a, b_, c: a | b_ | c)
+        b.BITOP3(t("neg5", w), H(w, 4), H(w, 3), t("o3", w), lambda a, b_, c: ~(a | b_ | c))
+        b.AND(t("bb", w), t("top", w), H(w, 2))                                   # 111xx
+        b.BITOP3(t("neg1", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & ~h2 & ~h1)
+        b.BITOP3(t("neg2", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & ~h2 & h1)
+        b.BITOP3(t("neg3", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & h2 & ~h1)
+        b.BITOP3(t("neg4", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & h2 & h1)
+        # columns holding any legal class, restricted to mismatches (:368-377):
+        # classes +2..0 = 110xx with xx != 00, classes -1..-4 = 111xx, class -5 = 00000
+        b.AND(t("vab", w), t("top", w), t("o3", w))
+        b.BITOP3(t("any", w), t("vab", w), t("neg5", w), E(w), lambda a, n5, e: (a | n5) & ~e)
+        # dV=+7: seeds where dH=-5 meets a match, carried along the remaining dH=-5 run
+        b.AND(t("seed", w), t("neg5", w), E(w))
+        b.BITOP3(t("run", w), t("neg5", w), E(w), E(w), lambda n5, e, _e: n5 & ~e)
+        (b.ADD_CO if w == 0 else b.ADDC)(t("sum", w), t("seed", w), t("neg5", w))
+        b.BITOP3(t("dv7m", w), t("sum", w), t("run", w), E(w), lambda s, r, e: (s ^ r) | e)
+
+    def shifted_run(seed_name, out_name):
+        """(:229-238) seed << 1 across words, added to the run with carry, toggled bits & ~match."""
+        for w in W:  # shift chain
+            (b.ADD_CO if w == 0 else b.ADDC)(t(seed_name, w), t(seed_name, w), t(seed_name, w))
+            if w + 1 < nw:
+                pass
+        for w in W:  # add chain
+            (b.ADD_CO if w == 0 else b.ADDC)(t("s_" + out_name, w), t(seed_name, w), t("run", w))
+            b.BITOP3(t(out_name, w), t("s_" + out_name, w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
+
+    # ---- dV = +6 (:224-238) ----------------------------------------------------------------------
+    for w in W:
+        b.AND(t("seed6", w), t("neg4", w), t("dv7m", w))
+    shifted_run("seed6", "dv6")
+    # ---- dV = +5 (:240-250) ----------------------------------------------------------------------
+    for w in W:
+        b.AND(t("seed5", w), t("neg3", w), t("dv7m", w))
+        b.BITOP3(t("seed5", w), t("neg4", w), t("dv6", w), t("seed5", w), lambda a, b_, c: (a & b_) | c)
+    shifted_run("seed5", "dv5")
+    # ---- dV = +4 (:252-264) ----------------------------------------------------------------------
+    for w in W:
+        b.AND(t("seed4", w), t("neg2", w), t("dv7m", w))
+        b.BITOP3(t("seed4", w), t("neg3", w), t("dv6", w), t("seed4", w), lambda a, b_, c: (a & b_) | c)
+        b.BITOP3(t("seed4", w), t("neg4", w), t("dv5", w), t("seed4", w), lambda a, b_, c: (a & b_) | c)
+    shifted_run("seed4", "dv4")
+    # ---- dV = +3 (:266-280) ----------------------------------------------------------------------
+    for w in W:
+        b.AND(t("seed3", w), t("neg1", w), t("dv7m", w))
+        b.BITOP3(t("seed3", w), t("neg2", w), t("dv6", w), t("seed3", w), lambda a, b_, c: (a & b_) | c)
+        b.BITOP3(t("seed3", w), t("neg3", w), t("dv5", w), t("seed3", w), lambda a, b_, c: (a & b_) | c)
+        b.BITOP3(t("seed3", w), t("neg4", w), t("dv4", w), t("seed3", w), lambda a, b_, c: (a & b_) | c)
+    shifted_run("seed3", "dv3")
+
+    # ---- encode dV (:281-297), dH + dV clamped at zero (:299-331) --------------------------------
+    for w in W:
+        b.BITOP3(t("x", w), t("dv7m", w), t("dv6", w), t("dv5", w), lambda a, b_, c: a | b_ | c)
+        b.BITOP3(t("rest", w), t("x", w), t("dv4", w), t("dv3", w), lambda a, b_, c: ~(a | b_ | c))
+        b.BITOP3(t("v0", w), t("rest", w), t("dv4", w), t("dv6", w), lambda a, b_, c: a | b_ | c)
+        b.BITOP3(t("v1", w), t("rest", w), t("dv5", w), t("dv6", w), lambda a, b_, c: a | b_ | c)
+        b.OR(t("v2", w), t("rest", w), t("dv7m", w))
+        # v3 = ~rest, v4 = 0
+        b.XOR(t("s0", w), H(w, 0), t("v0", w))
+        b.AND(t("c", w), H(w, 0), t("v0", w))
+        b.BITOP3(t("s1", w), H(w, 1), t("v1", w), t("c", w), lambda a, b_, c: a ^ b_ ^ c)
+        b.BITOP3(t("c", w), H(w, 1), t("v1", w), t("c", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
+        b.BITOP3(t("s2", w), H(w, 2), t("v2", w), t("c", w), lambda a, b_, c: a ^ b_ ^ c)
+        b.BITOP3(t("c", w), H(w, 2), t("v2", w), t("c", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
+        b.BITOP3(t("s3", w), H(w, 3), t("rest", w), t("c", w), lambda a, r, c: a ^ ~r ^ c)
+        b.BITOP3(t("c", w), H(w, 3), t("rest", w), t("c", w), lambda a, r, c: (a & ~r) | (a & c) | (~r & c))
+        b.XOR(t("s4", w), H(w, 4), t("c", w))
+        for i in range(4):
+            b.BITOP3(t(f"s{i}", w), t(f"s{i}", w), t("s4", w), t("s4", w), lambda s, k, _k: s & ~k)
+
+    # ---- new dH seed planes from match / mismatch (:368-391); they only need H, any, E -----------
+    def seed_planes(w):
+        b.BITOP3(t("g0", w), H(w, 0), t("any", w), E(w), lambda h, a, e: (h | a) & ~e)
+        b.BITOP3(t("g1", w), H(w, 1), t("any", w), E(w), lambda h, a, e: h & ~a & ~e)
+        b.BITOP3(t("g2", w), H(w, 2), t("any", w), E(w), lambda h, a, e: (h & ~a) | e)
+        b.BITOP3(t("g3", w), H(w, 3), t("any", w), E(w), lambda h, a, e: (h | a) & ~e)
+        b.BITOP3(t("g4", w), H(w, 4), t("any", w), E(w), lambda h, a, e: h | a | e)
+
+    # ---- shift the clamped sum one column up (:333-360): four chains; the seed-plane work is
+    #      interleaved so that consecutive links of a chain are two instructions apart ----------------
+    for i in range(4):
+        for w in W:
+            (b.ADD_CO if w == 0 else b.ADDC)(t(f"s{i}", w), t(f"s{i}", w), t(f"s{i}", w))
+            if i == 0:
+                seed_planes(w)
+
+    # ---- add the shifted sum to the seed planes and mask by sign (:393-426) ----------------------
+    for w in W:
+        b.XOR(t("r0", w), t("g0", w), t("s0", w))
+        b.AND(t("k", w), t("g0", w), t("s0", w))
+        b.BITOP3(t("r1", w), t("g1", w), t("s1", w), t("k", w), lambda a, b_, c: a ^ b_ ^ c)
+        b.BITOP3(t("k", w), t("g1", w), t("s1", w), t("k", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
+        b.BITOP3(t("r2", w), t("g2", w), t("s2", w), t("k", w), lambda a, b_, c: a ^ b_ ^ c)
+        b.BITOP3(t("k", w), t("g2", w), t("s2", w), t("k", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
+        b.BITOP3(t("r3", w), t("g3", w), t("s3", w), t("k", w), lambda a, b_, c: a ^ b_ ^ c)
+        b.BITOP3(t("k", w), t("g3", w), t("s3", w), t("k", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
+        b.XOR(H(w, 4), t("g4", w), t("k", w))
+        for i in range(4):
+            b.AND(H(w, i), t(f"r{i}", w), H(w, 4))
+    return b
+
+
+def bitpal_init_state(nw: int, lanes: int) -> list:
+    return [np.zeros(lanes, dtype=np.uint32) for _ in range(5 * nw)]  # all dH = -5 (:167-171)
+
+
+def bitpal_score(state: list, nw: int, qlen: int, slen: int) -> np.ndarray:
+    """(:433-471) score = -5*qlen + sum over subject columns of (16 b16 - 8 b8 - 4 b4 - 2 b2 - b1 - 5)."""
+    score = np.full(state[0].shape, -5 * qlen - 5 * slen, dtype=np.int64)
+    weights = (-1, -2, -4, -8, 16)
+    for w in range(nw):
+        rem = slen - 32 * w
+        mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
+        for i, wt in enumerate(weights):
+            score += wt * np.bitwise_count(state[w * 5 + i] & mask).astype(np.int64)
+    return score.astype(np.int16)
+
+
+# =================================================================================================
+# Reference-style match masks for the simulator (32 data bits per word)
+# =================================================================================================
+
+def build_peq32(subjects: np.ndarray, nw: int) -> np.ndarray:
+    """[5][nw][n_subjects] uint32; alphabet map of original/BGSA_CPU/global.c:9-15."""
+    n, slen = subjects.shape
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, c in zip(b"ACGTN", range(5)):
+        code[ch] = c
+    mapped = code[subjects]
+    peq = np.zeros((5, nw, n), dtype=np.uint32)
+    for p in range(slen):
+        for c in range(5):
+            peq[c, p // 32] |= ((mapped[:, p] == c).astype(np.uint32) << np.uint32(p % 32))
+    return peq
+
+
+def run_rows(body: Body, state: list, peq: np.ndarray, query: np.ndarray, groups: int = 1) -> None:
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+    nw = peq.shape[1]
+    for ch in query:
+        c = code.get(int(ch), 0)
+        eq = [peq[c, w] for _ in range(groups) for w in range(nw)]
+        body.simulate(state, eq)

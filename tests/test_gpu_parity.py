@@ -35,6 +35,15 @@ def test_myers_lengths_vs_oracle(oracle, slen):
     assert np.array_equal(got, oracle.myers64(q, s))
 
 
+@pytest.mark.parametrize("qlen", [1, 6, 7, 8, 13, 14, 15, 21, 49, 50])
+def test_query_stream_window_boundaries(oracle, qlen):
+    # the packed query stream holds 7 characters per 8-byte window: lengths around multiples of 7
+    q = oracle.gen_reads(700 + qlen, 9, qlen)
+    s = oracle.gen_reads(800 + qlen, 64, 40)
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), oracle.myers64(q, s))
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL), oracle.bitpal(q, s))
+
+
 def test_myers_query_tiles_and_offsets(oracle):
     # ref_start/ref_end windows and many queries (several q-tiles), odd row alignment (stride 151)
     q = oracle.gen_reads(31, 203, 150)
@@ -46,6 +55,24 @@ def test_myers_query_tiles_and_offsets(oracle):
     assert np.array_equal(a.score().cpu().numpy(), want)
     assert np.array_equal(a.score(100, 203).cpu().numpy(), want[100:203])
     assert np.array_equal(a.score(7, 8).cpu().numpy(), want[7:8])
+
+
+@pytest.mark.parametrize("slen", [1, 31, 32, 33, 64, 65, 100, 150, 200, 256])
+def test_bitpal_lengths_vs_oracle(oracle, slen):
+    qlen = max(1, slen - 2)
+    q = oracle.gen_reads(3000 + slen, 4, qlen)
+    s = oracle.gen_reads(4000 + slen, 70, slen)
+    m = min(qlen, slen)
+    s[:20, :m] = oracle.mutate(q[np.arange(20) % 4][:, :m], np.arange(20) % 7, slen)
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL), oracle.bitpal(q, s))
+
+
+def test_unsupported_lengths_fail_loudly(oracle):
+    q = oracle.gen_reads(1, 2, 64)
+    with pytest.raises(B.BgsaHipError):
+        B.align_all_pairs(q, oracle.gen_reads(2, 64, 1025), algo=B.ALGO_MYERS)
+    with pytest.raises(B.BgsaHipError):
+        B.align_all_pairs(q, oracle.gen_reads(2, 64, 257), algo=B.ALGO_BITPAL)
 
 
 def test_bad_arguments_fail_loudly():

@@ -1,0 +1,116 @@
+"""The generated GPU row bodies, interpreted on the CPU.
+
+bgsa_amd/csrc/rows_ir.py describes every DP row update as an instruction list; the same list
+is emitted as gfx950 assembly (myers_rows_gen.inc / bitpal_rows_gen.inc) and can be executed by
+a numpy interpreter.  Here the interpreter's scores must equal the oracle's bit for bit, which
+pins the instruction stream itself (truth tables, carry chains, phase order) without a GPU.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "bgsa_amd" / "csrc"))
+import rows_ir as R  # noqa: E402
+
+from conftest import load_golden  # noqa: E402
+
+
+def _inputs(oracle, seed, nq, ns, qlen, slen):
+    q = oracle.gen_reads(seed, nq, qlen)
+    s = oracle.gen_reads(seed + 1, ns, slen)
+    m = min(qlen, slen)
+    k = min(ns // 2, 24)
+    s[:k, :m] = oracle.mutate(q[np.arange(k) % nq][:, :m], np.arange(k) % 9, seed)
+    return q, s
+
+
+@pytest.mark.parametrize("qlen,slen", [(150, 150), (33, 31), (64, 64), (20, 100), (150, 140), (97, 161)])
+def test_myers_body_matches_oracle(oracle, qlen, slen):
+    q, s = _inputs(oracle, 500 + slen, 3, 48, qlen, slen)
+    nw = (slen + 31) // 32
+    body = R.myers_body(nw)
+    peq = R.build_peq32(s, nw)
+    want = oracle.myers64(q, s)
+    for i in range(q.shape[0]):
+        st = R.myers_init_state(nw, 1, s.shape[0])
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
+
+
+def test_myers_two_groups_per_wave(oracle):
+    q, s = _inputs(oracle, 77, 2, 32, 150, 150)
+    nw = 5
+    body = R.myers_body(nw, groups=2)
+    peq = R.build_peq32(s, nw)
+    want = oracle.myers64(q, s)
+    st = R.myers_init_state(nw, 2, s.shape[0])
+    R.run_rows(body, st, peq, q[1], groups=2)
+    for g in range(2):
+        assert np.array_equal(R.myers_score(st, nw, 150, 150, group=g), want[1])
+
+
+@pytest.mark.parametrize("qlen,slen", [(150, 150), (31, 31), (33, 32), (64, 65), (40, 100), (150, 140)])
+def test_bitpal_body_matches_oracle(oracle, qlen, slen):
+    q, s = _inputs(oracle, 900 + slen, 3, 48, qlen, slen)
+    nw = (slen + 31) // 32
+    body = R.bitpal_body(nw)
+    peq = R.build_peq32(s, nw)
+    want = oracle.bitpal(q, s)
+    for i in range(q.shape[0]):
+        st = R.bitpal_init_state(nw, s.shape[0])
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.bitpal_score(st, nw, qlen, slen), want[i])
+
+
+def test_bitpal_body_on_golden_specials(oracle):
+    g = load_golden("f5_bitpal_specials")
+    q, s = g["queries"][:2], g["subjects"]
+    nw = 5
+    body = R.bitpal_body(nw)
+    peq = R.build_peq32(s, nw)
+    for i in range(2):
+        st = R.bitpal_init_state(nw, s.shape[0])
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.bitpal_score(st, nw, 150, 150), g["scores"][i])
+
+
+def test_emitted_asm_respects_the_vcc_hazard():
+    for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5)):
+        lines = body.emit_asm(lambda name: name)
+        since = 99
+        for ln in lines:
+            if ln.startswith("s_nop"):
+                since += int(ln.split()[1]) + 1
+                continue
+            if ln.startswith("v_addc_co_u32"):
+                assert since >= 2, "carry-in read fewer than 2 instructions after a VCC write"
+            if ln.startswith(("v_addc_co_u32", "v_add_co_u32")) or ln.startswith("s_mov_b64 vcc"):
+                since = 0
+            else:
+                since += 1
+        # only fast-issue-class VALU opcodes may appear (scripts/ubench/valu_rate.hip)
+        allowed = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32", "v_bitop3_b32",
+                   "v_add_co_u32", "v_addc_co_u32", "s_nop", "s_mov_b64"}
+        assert {ln.split()[0] for ln in lines} <= allowed
+
+
+def test_temp_allocation_is_consistent():
+    for body in (R.myers_body(5), R.bitpal_body(5)):
+        slot_of, n = body.allocate_temps()
+        assert n <= len(body.temps())
+        # simulate with temporaries renamed to their slots: results must not change
+        renamed = R.Body()
+        for op in body.ops:
+            f = lambda r: r if (not r or r[0] in "SE") else f"slot{slot_of[r]}"
+            renamed.ops.append(R.Op(op.kind, f(op.dst), tuple(f(x) for x in op.srcs), op.imm))
+        rng = np.random.default_rng(1)
+        n_state = max(int(r[1:]) for op in body.ops for r in (op.dst,) + op.srcs if r.startswith("S")) + 1
+        n_eq = max(int(r[1:]) for op in body.ops for r in op.srcs if r.startswith("E")) + 1
+        st_a = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(n_state)]
+        eq = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(n_eq)]
+        st_b = [x.copy() for x in st_a]
+        body.simulate(st_a, eq)
+        renamed.simulate(st_b, eq)
+        assert all(np.array_equal(a, b) for a, b in zip(st_a, st_b))
