@@ -57,7 +57,7 @@ def algorithmic_ops_per_cell(algo: int, length: int, k: int) -> float:
 def algorithmic_bytes_per_pair(algo: int, length: int, wn: int, q_tile: int = 100) -> float:
     """score bytes + Peq bytes amortised over a query tile of REF_BUCKET_COUNT."""
     out = 1 if algo == B.ALGO_BANDED else 2
-    peq = B.group_words(algo, wn) * 4 / 64
+    peq = B.group_words(algo, wn, 8) * 4 / 64
     return out + peq / q_tile
 
 

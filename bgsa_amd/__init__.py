@@ -57,7 +57,7 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_last_error.restype = ctypes.c_char_p
     L.bgsa_hip_select_algorithm.argtypes = [i32]
     L.bgsa_hip_word_num.argtypes = [i32, i32, i32, i32]
-    L.bgsa_hip_group_words.argtypes = [i32, i32]
+    L.bgsa_hip_group_words.argtypes = [i32, i32, i32]
     L.bgsa_hip_group_words.restype = sz
     L.bgsa_hip_handle_reads_dev.argtypes = [i32, vp, i64, i32, i64, i32, i32, vp, vp]
     L.bgsa_hip_map_queries_dev.argtypes = [vp, i64, vp]
@@ -105,8 +105,8 @@ def word_num(algo: int, qlen: int, slen: int, k: int = 0) -> int:
     return int(lib().bgsa_hip_word_num(algo, qlen, slen, k))
 
 
-def group_words(algo: int, wn: int) -> int:
-    return int(lib().bgsa_hip_group_words(algo, wn))
+def group_words(algo: int, wn: int, k: int = 0) -> int:
+    return int(lib().bgsa_hip_group_words(algo, wn, k))
 
 
 def pad_rows(rows: np.ndarray, multiple: int = V_NUM) -> tuple[np.ndarray, int]:
@@ -181,7 +181,7 @@ class DeviceAligner:
         self.ns, self.slen = int(ns), int(slen)
         qlen = self.qlen if qlen is None else qlen
         self.wn = word_num(self.algo, qlen, self.slen, self.k)
-        n_words = group_words(self.algo, self.wn) * (self.ns // V_NUM)
+        n_words = group_words(self.algo, self.wn, self.k) * (self.ns // V_NUM)
         self.d_peq = torch.empty(n_words, dtype=torch.int32, device=self.device)
         check(lib().bgsa_hip_handle_reads_dev(self.algo, d_rows.data_ptr(), d_rows.numel(), self.slen,
                                               self.ns, self.wn, self.k, self.d_peq.data_ptr(),

@@ -1,10 +1,222 @@
-// banded.hip — banded Myers filter (placeholder until the kernel lands).
+// banded.hip — BGSA's banded Myers filter, one subject per lane, gfx950.
+//
+// Replaces the reference's banded align_cpu (banded/BGSA_CPU/align_core.c:69-252) and its
+// preprocess (banded/BGSA_CPU/global.c:25-84).  Output: int8, the band-limited distance
+// (minimum over the last row inside the band) or MAX_ERROR = 127 when the running error on the
+// lowest diagonal exceeds k + h + 1 at the reference's last checkpoint.
+//
+// What the reference does per row, per pair: one Hyyrö step on a single 64-bit word that slides
+// down the diagonal (cpu_cal_D0, :19-33), then shifts FIVE 64-bit match windows right by one and
+// feeds each a new bit (cpu_move_peq / cpu_or_peq, :35-62) — 30 of its 42 ops per row move
+// windows.  Here the windows are never moved: the preprocess stores, per character class, the
+// subject's match bit-string offset by k+1 zero bits ("Mext": bit i = subject[i-(k+1)] == c), and
+// the window of row r is just the band_length bits of Mext starting at bit r — one funnel shift
+// with a wave-uniform amount, for the current query character only.  That is exactly the window
+// the reference holds at row r (DESIGN.md "banded"): word 0 of its layout is Mext bits 0..2k,
+// and each row's shift-and-feed advances the same bit-string by one.
+//
+// Early exit: the reference tests err > max_err after row min(64, m), then every 16 rows, last at
+// row max(64, n-h) (:136-140,170-174,199-203,216-220).  err never decreases, so a pair is rejected iff the
+// test holds at that LAST checkpoint; any earlier test that fires implies it.  A wave therefore
+// tests every 16 rows from the start and stops as soon as all 64 lanes are past the limit.
+//
+// Band of 2k+1 (+1 carry) bits: 32-bit words for k <= 15, 64-bit words for k <= 31.
+// Supported domain: query_len == subject_len (the reference's band is mis-aligned otherwise,
+// SURVEY.md §8(a) A5) — anything else is refused loudly.
 #include "bgsa_common.h"
+
 namespace bgsa {
-const char *banded_kernel_name(int) { return "banded_kernel"; }
-int launch_banded(const char *, const uint32_t *, int8_t *, int, int, int64_t, int, int, int, int, hipStream_t)
+
+template <typename T>
+struct BandWord;
+template <>
+struct BandWord<uint32_t> {
+    static constexpr int bits = 32;
+    // bits [sh, sh+32) of the 64-bit pair {hi:lo}; sh is wave-uniform in 0..31
+    static __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, int sh)
+    {
+        return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> sh);
+    }
+};
+template <>
+struct BandWord<uint64_t> {
+    static constexpr int bits = 64;
+    static __device__ __forceinline__ uint64_t funnel(uint64_t hi, uint64_t lo, int sh)
+    {
+        return sh == 0 ? lo : ((lo >> sh) | (hi << (64 - sh)));
+    }
+};
+
+// One row (cpu_cal_D0 :19-33 + cpu_cal_score :64-67).  `win` already masked to the band.
+template <typename T>
+__device__ __forceinline__ void band_row(T win, T &vp, T &vn, uint32_t &acc)
 {
-    set_error_text("banded: kernel not built yet");
+    const T x = win | vn;
+    const T d0 = (((x & vp) + vp) ^ vp) | x;
+    const T hn = d0 & vp;
+    const T hp = ~(d0 | vp) | vn;
+    const T x2 = d0 >> 1;
+    vn = x2 & hp;
+    vp = ~(hp | x2) | hn;
+    acc += 1u - static_cast<uint32_t>(d0 & 1);
+}
+
+// Rows [WI*W, WI*W+W) of one query; recursion over WI keeps every M[][] index a constant.
+template <typename T, int NX, int WI>
+struct BandChunks {
+    static __device__ __forceinline__ void run(const T (&M)[kChars][NX], UniformBytes &qs, T &vp, T &vn,
+                                               uint32_t &acc, bool &dead, bool &all_dead, int len, int k,
+                                               T band_mask, uint32_t max_err, int last_check)
+    {
+        constexpr int W = BandWord<T>::bits;
+        if (!all_dead) {
+            for (int j = 0; j < W; j++) {
+                const int r = WI * W + j;
+                if (r >= len || all_dead) break;
+                if ((r & 3) == 0) qs.refill(r, len - r);
+                const uint32_t c = __builtin_amdgcn_readfirstlane(qs.next());
+                // (the per-case asm comments keep hipcc from folding the switch into a dynamically
+                // indexed load of M[c][WI], which would push M[][] into scratch memory)
+                T win;
+                switch (c) {
+                case 0: win = BandWord<T>::funnel(M[0][WI + 1], M[0][WI], j); asm volatile("; class 0" : "+v"(win)); break;
+                case 1: win = BandWord<T>::funnel(M[1][WI + 1], M[1][WI], j); asm volatile("; class 1" : "+v"(win)); break;
+                case 2: win = BandWord<T>::funnel(M[2][WI + 1], M[2][WI], j); asm volatile("; class 2" : "+v"(win)); break;
+                case 3: win = BandWord<T>::funnel(M[3][WI + 1], M[3][WI], j); asm volatile("; class 3" : "+v"(win)); break;
+                default: win = BandWord<T>::funnel(M[4][WI + 1], M[4][WI], j); asm volatile("; class 4" : "+v"(win)); break;
+                }
+                if (r == k) acc = 0;  // scoring starts at row k with err = k (:116-134)
+                band_row<T>(win & band_mask, vp, vn, acc);
+                const int done = r + 1;
+                if (done <= last_check && ((done & 15) == 0 || done == last_check)) {
+                    const bool over = done > k && (static_cast<uint32_t>(k) + acc > max_err);
+                    if (done == last_check) dead = over;
+                    if (__builtin_amdgcn_ballot_w64(!over) == 0) {  // every lane is past the limit
+                        dead = true;
+                        all_dead = true;
+                    }
+                }
+            }
+        }
+        BandChunks<T, NX, WI + 1>::run(M, qs, vp, vn, acc, dead, all_dead, len, k, band_mask, max_err, last_check);
+    }
+};
+template <typename T, int NX>
+struct BandChunks<T, NX, NX - 1> {
+    static __device__ __forceinline__ void run(const T (&)[kChars][NX], UniformBytes &, T &, T &, uint32_t &,
+                                               bool &, bool &, int, int, T, uint32_t, int) {}
+};
+
+// NX = words of Mext kept in registers per character class (incl. one zero spare for the funnel).
+template <typename T, int NX>
+__global__ __launch_bounds__(256) void banded_kernel(
+    const char *__restrict__ content, const T *__restrict__ mext, int8_t *__restrict__ out,
+    int len, long long ld, int n_groups, int word_num, int ref_start, int ref_end, int q_tile, int k)
+{
+    constexpr int W = BandWord<T>::bits;
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (group >= n_groups) return;
+
+    T M[kChars][NX];
+    const T *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+#pragma unroll
+    for (int c = 0; c < kChars; c++)
+#pragma unroll
+        for (int w = 0; w < NX; w++) M[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : T(0);
+
+    const int h = k;                       // h_threshold = k + n - m with n == m (:70)
+    const int band_down = k + h;           // band_length - 1 (:71-72)
+    const T band_mask = (band_down + 1 >= W) ? ~T(0) : ((T(1) << (band_down + 1)) - 1);
+    const uint32_t max_err = static_cast<uint32_t>(k + h + 1);  // :114
+    // Row count after which the reference runs its last test: after the first min(64, m) rows
+    // (:125-140) and, for m > 64, again when its feed index reaches n, i.e. after n-h rows
+    // (:216-220) — whichever is later; the final k rows are never tested (:221-226).
+    const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
+
+    const int q0 = ref_start + blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < ref_end) ? q0 + q_tile : ref_end;
+    int8_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        T vp = 0, vn = 0;                  // :96-97
+        uint32_t acc = 0;                  // err - k; rows < k do not score (:116-123)
+        bool dead = false;
+        bool all_dead = false;
+        UniformBytes qs(content + static_cast<size_t>(q) * (len + 1));
+        // Rows wi*W .. wi*W+W-1 read the window from Mext words wi and wi+1: one statically
+        // indexed chunk per word so that M[][] stays in registers.
+        BandChunks<T, NX, 0>::run(M, qs, vp, vn, acc, dead, all_dead, len, k, band_mask, max_err, last_check);
+        // :230-245 — walk the last row across the band, keep the minimum.
+        uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
+        for (int i = 0; i <= h; i++) {
+            err += static_cast<uint32_t>((vp >> i) & 1);
+            err -= static_cast<uint32_t>((vn >> i) & 1);
+            best = err < best ? err : best;
+        }
+        dst[static_cast<size_t>(q - ref_start) * ld] = dead ? static_cast<int8_t>(HIP_MAX_ERROR) : static_cast<int8_t>(best);
+    }
+}
+
+namespace {
+
+template <typename T, int NX>
+int launch_nx(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len,
+              int64_t read_count, int ref_start, int ref_end, int word_num, int k, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    int q_tile = 32;
+    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("banded: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL((banded_kernel<T, NX>), grid, dim3(256), 0, stream, d_content,
+                       reinterpret_cast<const T *>(d_peq), d_results, len,
+                       static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, ref_start,
+                       ref_end, q_tile, k);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+}  // namespace
+
+const char *banded_kernel_name(int word_num)
+{
+    static thread_local char name[64];
+    snprintf(name, sizeof name, "banded_kernel<%d words>", word_num);
+    return name;
+}
+
+int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
+                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, int k,
+                  hipStream_t stream)
+{
+    if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
+    if (ref_len != read_len) {
+        set_error_text("banded: query_len must equal subject_len (the reference's band is mis-aligned otherwise)");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (k < 1 || k > 31 || 2 * k + 1 >= read_len) {
+        set_error_text("banded: threshold must satisfy 1 <= k <= 31 and 2k+1 < length");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+#define BGSA_BANDED(T, NX)                                                                          \
+    if (word_num <= NX)                                                                             \
+        return launch_nx<T, NX>(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, \
+                                word_num, k, stream);
+    if (k <= 15) {
+        BGSA_BANDED(uint32_t, 4) BGSA_BANDED(uint32_t, 7) BGSA_BANDED(uint32_t, 10)
+        BGSA_BANDED(uint32_t, 18) BGSA_BANDED(uint32_t, 34)
+    } else {
+        BGSA_BANDED(uint64_t, 3) BGSA_BANDED(uint64_t, 5) BGSA_BANDED(uint64_t, 9) BGSA_BANDED(uint64_t, 18)
+    }
+#undef BGSA_BANDED
+    set_error_text("banded: subjects longer than ~1000 bp are not supported yet");
     return BGSA_HIP_EUNSUPPORTED;
 }
+
 }  // namespace bgsa

@@ -119,17 +119,18 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k)
     case BGSA_ALGO_MYERS: return (subject_len + 31) / 32;   // cal_cpu.c:252-253, full_bits
     case BGSA_ALGO_BITPAL: return (subject_len + 31) / 32;  // same layout as Myers
     case BGSA_ALGO_BANDED: {
-        const int h = k + subject_len - query_len;           // banded cal_cpu.c:253-254
-        return (subject_len - h + 63) / 64 + 1;
+        (void)query_len;                                     // equal lengths only (banded.hip)
+        const int w = k <= 15 ? 32 : 64;                     // band of 2k+2 bits per word
+        return (subject_len + w - 1) / w + 1;                // + one zero word for the funnel shift
     }
     default: return -1;
     }
 }
 
-size_t bgsa_hip_group_words(int algo, int word_num)
+size_t bgsa_hip_group_words(int algo, int word_num, int k)
 {
     const size_t per = static_cast<size_t>(BGSA_CHAR_NUM) * word_num * HIP_V_NUM;
-    return algo == BGSA_ALGO_BANDED ? 2 * per : per;
+    return (algo == BGSA_ALGO_BANDED && k > 15) ? 2 * per : per;
 }
 
 // ---- device-resident layer ---------------------------------------------------------------------
@@ -287,7 +288,7 @@ void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_
     (void)dvdh_bit_mem;    // per-thread scratch of the CPU kernels; state lives in VGPRs here
     if (ref_end <= ref_start || read_count <= 0) return;
     const size_t content_bytes = static_cast<size_t>(ref_count) * (ref_len + 1);
-    const size_t peq_bytes = bgsa_hip_group_words(g_algo, word_num) * sizeof(hip_read_t) *
+    const size_t peq_bytes = bgsa_hip_group_words(g_algo, word_num, threshold) * sizeof(hip_read_t) *
                              (static_cast<size_t>(read_count) / HIP_V_NUM);
     const size_t res_bytes = static_cast<size_t>(ref_end - ref_start) * read_count * result_elem_size(g_algo);
     if (g_ws.reserve(&g_ws.d_content, &g_ws.cap_content, content_bytes + 8) ||

@@ -43,9 +43,11 @@ def test_word_num(L):
     assert B.word_num(B.ALGO_MYERS, 150, 150) == 5
     assert B.word_num(B.ALGO_MYERS, 1000, 1000) == 32
     assert B.word_num(B.ALGO_MYERS, 1, 32) == 1 and B.word_num(B.ALGO_MYERS, 1, 33) == 2
-    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 4
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 6   # 32-bit words of the offset match string + spare
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 16) == 4  # 64-bit words above k = 15
     assert B.group_words(B.ALGO_MYERS, 5) == 5 * 5 * 64
-    assert B.group_words(B.ALGO_BANDED, 4) == 2 * 5 * 4 * 64
+    assert B.group_words(B.ALGO_BANDED, 6, 8) == 5 * 6 * 64
+    assert B.group_words(B.ALGO_BANDED, 4, 16) == 2 * 5 * 4 * 64
 
 
 def test_mapping_table(L):
@@ -60,7 +62,7 @@ def _host_preprocess(L, algo, rows, k=0, qlen=None):
     n, length = rows.shape
     buf = B.rows_to_buffer(rows)
     wn = B.word_num(algo, length if qlen is None else qlen, length, k)
-    out = np.zeros(B.group_words(algo, wn) * (n // 64), dtype=np.uint32)
+    out = np.zeros(B.group_words(algo, wn, k) * (n // 64), dtype=np.uint32)
     seq = B.SeqT(len=length, size=buf.size, count=n, extra_size=0, extra_count=0, content=buf.ctypes.data)
     assert L.bgsa_hip_select_algorithm(algo) == 0
     ctypes.c_int.in_dll(L, "threshold").value = k
@@ -90,13 +92,16 @@ def test_host_handle_reads_layout_myers(L, oracle):
 
 
 def test_host_handle_reads_layout_banded(L, oracle):
+    # Mext: bit i of plane c is set iff i >= k+1 and subject[i-(k+1)] == c (32-bit words, k <= 15)
     rows = oracle.gen_reads(78, 64, 150)
-    k = 8
-    rows, peq, wn = _host_preprocess(L, B.ALGO_BANDED, rows, k=k)
-    assert wn == 4
-    peq = peq.view(np.uint64).reshape(-1, 5, wn, 64)
-    s = 5
-    for p in range(k):  # word 0: first k characters at bits k+1 .. 2k
-        assert (int(peq[0, CODE[rows[s, p]], 0, s]) >> (k + 1 + p)) & 1
-    for i in range(150 - k):  # words 1..: characters from index k, 64 per word
-        assert (int(peq[0, CODE[rows[s, k + i]], 1 + i // 64, s]) >> (i % 64)) & 1
+    for k, dtype, W in ((8, np.uint32, 32), (16, np.uint64, 64)):
+        padded, peq, wn = _host_preprocess(L, B.ALGO_BANDED, rows, k=k)
+        assert wn == (150 + W - 1) // W + 1
+        peq = peq.view(dtype).reshape(-1, 5, wn, 64)
+        s = 5
+        for p in range(150):
+            i = p + k + 1
+            for cc in range(5):
+                bit = (int(peq[0, cc, i // W, s]) >> (i % W)) & 1
+                assert bit == (cc == CODE[padded[s, p]])
+        assert int(np.bitwise_count(peq[0, :, :, s]).sum()) == 150

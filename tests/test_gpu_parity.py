@@ -67,6 +67,25 @@ def test_bitpal_lengths_vs_oracle(oracle, slen):
     assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL), oracle.bitpal(q, s))
 
 
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (150, 15), (150, 16), (150, 31), (64, 8), (65, 8), (73, 8),
+                                      (100, 12), (128, 8), (136, 8), (200, 8), (250, 20), (500, 8), (1000, 8)])
+def test_banded_vs_oracle(oracle, length, k):
+    # includes lengths (65, 136, 200) where the reference itself writes out of bounds: the oracle
+    # (and the kernel) follow the in-bounds semantics there (DESIGN.md "banded domain")
+    q = oracle.gen_reads(5000 + length + k, 6, length)
+    s = oracle.gen_reads(6000 + length + k, 130, length)
+    s[:60] = oracle.mutate(q[np.arange(60) % 6], np.arange(60) % (2 * k + 6), length + k)
+    got = B.align_all_pairs(q, s, algo=B.ALGO_BANDED, k=k)
+    want = oracle.banded64(q, s, k)
+    assert got.dtype == np.int8 and np.array_equal(got, want)
+    assert (want != 127).any() and (want == 127).any()
+
+
+def test_banded_refuses_unequal_lengths(oracle):
+    with pytest.raises(B.BgsaHipError):
+        B.align_all_pairs(oracle.gen_reads(1, 2, 140), oracle.gen_reads(2, 64, 150), algo=B.ALGO_BANDED, k=8)
+
+
 def test_unsupported_lengths_fail_loudly(oracle):
     q = oracle.gen_reads(1, 2, 64)
     with pytest.raises(B.BgsaHipError):
