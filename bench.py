@@ -61,6 +61,38 @@ def algorithmic_bytes_per_pair(algo: int, length: int, wn: int, q_tile: int = 10
     return out + peq / q_tile
 
 
+def issued_valu_per_row(algo: int, wn: int):
+    """VALU instructions the shipped row body issues per (query row, wave), from the generator's
+    own instruction lists (bgsa_amd/csrc/rows_ir.py); None for the compiler-scheduled kernels."""
+    sys.path.insert(0, str(ROOT / "bgsa_amd" / "csrc"))
+    try:
+        import rows_ir as R
+    except Exception:
+        return None
+    if algo == B.ALGO_MYERS and wn <= 8:
+        return R.myers_body(wn).valu_count()
+    if algo == B.ALGO_MYERS and wn <= 32:
+        return None
+    if algo == B.ALGO_BITPAL and wn <= 8:
+        return R.bitpal_body(wn).valu_count()
+    return None
+
+
+def pmc_traffic(config: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc.csv): separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md §HBM (it tallies 128-B requests at 64 B)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(str(ROOT / "profiles" / f"*cfg{config}_pmc.csv")))
+    if not files:
+        return None
+    vals = {r["counter"]: float(r["value_per_launch"]) for r in csv.DictReader(open(files[-1]))}
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return {"bytes": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024, "source": Path(files[-1]).name}
+
+
 def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> dict:
     """Time the CPU path on a bounded sample of the same workload, on this node's host cores."""
     import oracle as O
@@ -187,6 +219,13 @@ def main() -> int:
         achieved_ops = kernel_gcups * 1e9 * ops_cell
         pairs_per_s = float(nq) * ns / kernel_s
         bpp = algorithmic_bytes_per_pair(algo, length, wn)
+        vpr = issued_valu_per_row(algo, wn)
+        issued = None
+        if vpr:
+            issued_ops = vpr * 64.0 * (float(nq) * (ns_pad // 64) * length) / kernel_s
+            issued = {"valu_per_row": vpr, "achieved": round(issued_ops / 1e12, 2), "unit": "Tops/s",
+                      "frac": round(issued_ops / VALU_PEAK_OPS, 4)}
+        traffic = pmc_traffic(args.config) if not overridden else None
         result = {
             "metric": "GCUPS (cell updates/sec) all-pairs Myers 150bp" if args.config == 2 else f"GCUPS ({cfg_name})",
             "value": round(gcups, 2),
@@ -209,9 +248,12 @@ def main() -> int:
                 "peak": round(VALU_PEAK_OPS / 1e12, 2),
                 "unit": "Tops/s",
                 "frac": round(achieved_ops / VALU_PEAK_OPS, 4),
-                "traffic": None,
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
                 "note": "32-bit integer VALU issue bound (SURVEY §8(d)); achieved = GCUPS x the reference's "
-                        f"{ops_cell:.3f} ALU ops/cell; kernel time from HIP events on the launch stream",
+                        f"{ops_cell:.3f} ALU ops/cell (a frac > 1 means the kernel needs fewer ops than the "
+                        "reference counts: see `issued`); kernel time from HIP events on the launch stream",
+                "issued": issued,
                 "kernel_ms": round(kernel_s * 1e3, 3),
                 "kernel_gcups": round(kernel_gcups, 1),
                 "hbm": {"bound": "hbm", "achieved": round(pairs_per_s * bpp / 1e9, 2), "peak": HBM_PEAK / 1e9,

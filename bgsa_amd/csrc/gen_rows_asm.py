@@ -29,6 +29,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 import rows_ir as R  # noqa: E402
 
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8]
+MYERS_PLANES_NW = [12, 16, 20, 24, 28, 32]
 BITPAL_NW = [1, 2, 3, 4, 5, 6, 7, 8]
 
 # Scalar scratch registers, hard-coded and declared as clobbers (inline asm cannot name the
@@ -55,7 +56,9 @@ def dispatch() -> list[str]:
     ]
 
 
-def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n_eq: int) -> str:
+def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n_eq: int,
+                 n_planes: int = 0) -> str:
+    """n_planes > 0: the body reads class-independent code planes B[] instead of per-class masks."""
     slot_of, n_slots = body.allocate_temps()
 
     def reg_for(c: int):
@@ -64,6 +67,8 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
                 return f"%[s{name[1:]}]"
             if name.startswith("E"):
                 return f"%[e{c}_{name[1:]}]"
+            if name.startswith("B"):
+                return f"%[b{name[1:]}]"
             return f"%[t{slot_of[name]}]"
         return reg
 
@@ -82,7 +87,7 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
     asm += dispatch()
     for c in range(5):
         asm.append(f"L_body{c}_%=:")
-        asm += body.emit_asm(reg_for(c))
+        asm += body.emit_asm(reg_for(c), c)
         asm += dispatch()
     # END (code 5) and REFILL (code 6) live in slots of the same stride as the row bodies.
     asm.append("L_body5_%=:")
@@ -107,16 +112,21 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = [f'[e{c}_{j}] "v"(P[{c}][{j}])' for c in range(5) for j in range(n_eq)]
+    if n_planes:
+        ins = [f'[b{j}] "v"(B[{j}])' for j in range(n_planes)]
+        masks_param = f"const uint32_t (&B)[{n_planes}]"
+    else:
+        ins = [f'[e{c}_{j}] "v"(P[{c}][{j}])' for c in range(5) for j in range(n_eq)]
+        masks_param = f"const uint32_t (&P)[5][{n_eq}]"
     ins.append('[qp] "s"(stream)')
     ins.append('[nwin] "s"(n_windows)')
     clob = ", ".join(f'"{c}"' for c in CLOBBERS)
-    nops = sum(line.startswith("s_nop") for line in body.emit_asm(lambda x: x))
+    nops = sum(line.startswith("s_nop") for line in body.emit_asm(lambda x: x, 0))
     return f"""
 // {body.valu_count()} VALU per row, {n_slots} temporaries, {nops} hazard nops
 template <>
 __device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
-                                                   const uint32_t (&P)[5][{n_eq}],
+                                                   {masks_param},
                                                    const unsigned long long stream,
                                                    const int n_windows)
 {{
@@ -147,6 +157,13 @@ def main() -> int:
         for g in (1, 2):
             if nw * g <= 10:
                 parts.append(gen_function("myers_rows_asm", f"{nw}, {g}", R.myers_body(nw, g), 2 * nw * g, nw * g))
+    parts.append("\n// Long subjects (NW 9..32): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ void myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"
+                 "                                                      const uint32_t (&B)[3 * NW],\n"
+                 "                                                      const unsigned long long stream, const int n_windows);\n")
+    for nw in MYERS_PLANES_NW:
+        parts.append(gen_function("myers_planes_rows_asm", f"{nw}", R.myers_planes_body(nw), 2 * nw, 0, n_planes=3 * nw))
     (here / "myers_rows_gen.inc").write_text("".join(parts))
     # ---- BitPAl -------------------------------------------------------------------------------
     parts = [head,

@@ -182,6 +182,57 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     }
 }
 
+// Long subjects (257..1024 bp): the wave turns its five Peq planes into the subject's 3-bit
+// character-code planes once per task (B0 = C|T, B1 = G|T, B2 = N) and the row body rebuilds the
+// match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 11 VALU per
+// word, 7*NW+1 registers, two waves per SIMD at NW = 32.
+template <int NW>
+__global__ __launch_bounds__(256) void myers_global_planes_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
+    int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (group >= n_groups) return;
+
+    uint32_t Bp[3 * NW];
+    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t p[kChars];
+#pragma unroll
+        for (int c = 0; c < kChars; c++) p[c] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+        Bp[3 * w + 0] = p[1] | p[3];
+        Bp[3 * w + 1] = p[2] | p[3];
+        Bp[3 * w + 2] = p[4];
+    }
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        uint32_t st[2 * NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            st[2 * w] = ~0u;
+            st[2 * w + 1] = 0u;
+        }
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        myers_planes_rows_asm<NW>(st, Bp, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        int score = ref_len;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int rem = read_len - 32 * w;
+            const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+            score += __popc(st[2 * w] & m) - __popc(st[2 * w + 1] & m);
+        }
+        dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(-score);
+    }
+}
+
 namespace {
 
 // Register-resident word counts that are instantiated; a subject uses the smallest one that
@@ -238,6 +289,37 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     return BGSA_HIP_OK;
 }
 
+template <int NW>
+int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+                  void *d_workspace, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    int q_tile = 8;  // a task is already long: 8 queries x ref_len rows x 11*NW instructions
+    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("myers: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    hipLaunchKernelGGL((myers_global_planes_kernel<NW>), grid, dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                       read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)));
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+int pick_planes_nw(int word_num)
+{
+    for (int nw : {12, 16, 20, 24, 28, 32})
+        if (nw >= word_num) return nw;
+    return -1;
+}
+
 template <int NW, int G>
 int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
               int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
@@ -266,7 +348,10 @@ const char *myers_kernel_name(int word_num)
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
     if (nw < 0) return "myers_global_kernel<unsupported>";
-    snprintf(name, sizeof name, "%s<%d, 1>", (nw <= 8 && myers_impl() == 0) ? "myers_global_asm_kernel" : "myers_global_kernel", nw);
+    if (myers_impl() == 0 && word_num > 8 && pick_planes_nw(word_num) > 0)
+        snprintf(name, sizeof name, "myers_global_planes_kernel<%d>", pick_planes_nw(word_num));
+    else
+        snprintf(name, sizeof name, "%s<%d, 1>", (nw <= 8 && myers_impl() == 0) ? "myers_global_asm_kernel" : "myers_global_kernel", nw);
     return name;
 }
 
@@ -284,6 +369,16 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             BGSA_ASM_CASE(1) BGSA_ASM_CASE(2) BGSA_ASM_CASE(3) BGSA_ASM_CASE(4) BGSA_ASM_CASE(5)
             BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8)
 #undef BGSA_ASM_CASE
+        default: break;
+        }
+        switch (word_num > 8 ? pick_planes_nw(word_num) : -1) {
+#define BGSA_PLANES_CASE(N)                                                                     \
+    case N:                                                                                     \
+        return launch_planes<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,     \
+                                ref_start, ref_end, word_num, d_workspace, stream);
+            BGSA_PLANES_CASE(12) BGSA_PLANES_CASE(16) BGSA_PLANES_CASE(20) BGSA_PLANES_CASE(24)
+            BGSA_PLANES_CASE(28) BGSA_PLANES_CASE(32)
+#undef BGSA_PLANES_CASE
         default: break;
         }
     }

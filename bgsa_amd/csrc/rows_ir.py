@@ -69,12 +69,19 @@ class Body:
     def ADDC(self, d, a, b): return self._emit("addc", d, a, b)       # d = a + b + VCC, VCC = carry out
     def SETC1(self): return self._emit("setc1", "")                    # VCC = all ones (carry-in 1)
 
+    def MATCH3(self, d, b0, b1, b2):
+        """d = columns whose 3-bit character code (b2 b1 b0) equals the row's class (0..4 = A C G T
+        N): a v_bitop3 whose truth table depends on which of the five body copies it sits in."""
+        tts = tuple(tt(lambda x0, x1, x2, c=c: (x0 if c & 1 else ~x0) & (x1 if c & 2 else ~x1) & (x2 if c & 4 else ~x2))
+                    for c in range(5))
+        return self._emit("match3", d, b0, b1, b2, imm=tts)
+
     # ---- analysis ---------------------------------------------------------------------------
     def temps(self) -> list[str]:
         seen = []
         for op in self.ops:
             for r in (op.dst,) + op.srcs:
-                if r and not r.startswith(("S", "E")) and r not in seen:
+                if r and not r.startswith(("S", "E", "B")) and r not in seen:
                     seen.append(r)
         return seen
 
@@ -83,7 +90,7 @@ class Body:
         last_use = {}
         for i, op in enumerate(self.ops):
             for r in (op.dst,) + op.srcs:
-                if r and not r.startswith(("S", "E")):
+                if r and not r.startswith(("S", "E", "B")):
                     last_use[r] = i
         slot_of, free, n_slots = {}, [], 0
         for i, op in enumerate(self.ops):
@@ -93,7 +100,7 @@ class Body:
             for r in dying:
                 free.append(slot_of[r])
             d = op.dst
-            if d and not d.startswith(("S", "E")) and d not in slot_of:
+            if d and not d.startswith(("S", "E", "B")) and d not in slot_of:
                 if free:
                     slot_of[d] = free.pop()
                 else:
@@ -107,8 +114,9 @@ class Body:
         return sum(op.kind != "setc1" for op in self.ops)
 
     # ---- numpy interpreter --------------------------------------------------------------------
-    def simulate(self, state: list, eq: list) -> None:
-        """state: list of uint32 arrays (updated in place); eq: list of uint32 arrays."""
+    def simulate(self, state: list, eq: list, cls: int = 0, planes: list | None = None) -> None:
+        """state: list of uint32 arrays (updated in place); eq: match masks of the row's class
+        ('E' registers); planes: the class-independent 'B' registers; cls: the row's class."""
         regs: dict[str, np.ndarray] = {}
         vcc = np.zeros_like(state[0], dtype=bool)
 
@@ -117,6 +125,8 @@ class Body:
                 return state[int(name[1:])]
             if name.startswith("E"):
                 return eq[int(name[1:])]
+            if name.startswith("B"):
+                return planes[int(name[1:])]
             return regs[name]
 
         def wr(name, val):
@@ -138,11 +148,12 @@ class Body:
             elif k == "xor": wr(op.dst, s[0] ^ s[1])
             elif k == "not": wr(op.dst, s[0] ^ FULL)
             elif k == "mov": wr(op.dst, s[0])
-            elif k == "bitop3":
+            elif k in ("bitop3", "match3"):
                 a, b, c = s
+                imm = op.imm if k == "bitop3" else op.imm[cls]
                 out = np.zeros_like(a)
                 for idx in range(8):
-                    if (op.imm >> idx) & 1:
+                    if (imm >> idx) & 1:
                         ta = a if idx & 4 else a ^ FULL
                         tb = b if idx & 2 else b ^ FULL
                         tc = c if idx & 1 else c ^ FULL
@@ -158,8 +169,9 @@ class Body:
                 raise ValueError(k)
 
     # ---- gfx950 assembly ------------------------------------------------------------------------
-    def emit_asm(self, reg_name) -> list[str]:
-        """reg_name(name) -> asm operand text.  Returns instruction lines with hazard padding."""
+    def emit_asm(self, reg_name, cls: int = 0) -> list[str]:
+        """reg_name(name) -> asm operand text; cls = character class of this body copy.
+        Returns instruction lines with hazard padding."""
         lines: list[str] = []
         since_vcc_write = 99  # instructions issued since the last write of VCC
         for op in self.ops:
@@ -179,6 +191,7 @@ class Body:
             elif k == "not": lines.append(f"v_not_b32 {d}, {r[0]}")
             elif k == "mov": lines.append(f"v_mov_b32 {d}, {r[0]}")
             elif k == "bitop3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm:02x}")
+            elif k == "match3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm[cls]:02x}")
             elif k == "add_co": lines.append(f"v_add_co_u32 {d}, vcc, {r[0]}, {r[1]}")
             elif k == "addc": lines.append(f"v_addc_co_u32 {d}, vcc, {r[0]}, {r[1]}, vcc")
             else:
@@ -222,6 +235,44 @@ def myers_body(nw: int, groups: int = 1) -> Body:
             b.AND(M(w), D(w), HP(w))
             b.BITOP3(P(w), D(w), HP(w), HN(w), lambda d, hp, hn: ~(d | hp) | hn)
     return b
+
+
+def myers_planes_body(nw: int) -> Body:
+    """Myers for long subjects (257..1024 bp): the five Peq planes of a subject (5*nw registers)
+    are replaced by its 3-bit character code planes B[w*3+i] (3*nw registers) and the match mask
+    of the row's class is rebuilt per word with one v_bitop3 (MATCH3) — 11 instructions per word,
+    7*nw+1 registers, which keeps 32 words (1024 bp) at two waves per SIMD.  State as myers_body.
+    """
+    b = Body()
+    P = lambda w: f"S{w * 2}"
+    M = lambda w: f"S{w * 2 + 1}"
+    D = lambda w: f"d{w}"
+    HP = lambda w: f"hp{w}"
+    for w in range(nw):  # phase A
+        b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}")
+        b.AND(D(w), P(w), "e")
+        (b.ADD_CO if w == 0 else b.ADDC)(D(w), D(w), P(w))
+        b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
+        b.OR(D(w), D(w), "e")
+    b.SETC1()
+    for w in range(nw):  # phase C: HP chain; HN parks in the VP register, the new VN is final
+        b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
+        b.AND(P(w), D(w), P(w))            # HN
+        b.ADDC(HP(w), HP(w), HP(w))
+        b.AND(M(w), D(w), HP(w))
+    for w in range(nw):  # phase D: HN chain in place, then the new VP
+        (b.ADD_CO if w == 0 else b.ADDC)(P(w), P(w), P(w))
+        b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
+    return b
+
+
+def code_planes(peq: np.ndarray) -> list:
+    """[5][nw][n] Peq -> class-independent code planes B[w*3+i] (A=0 C=1 G=2 T=3 N=4)."""
+    nw = peq.shape[1]
+    out = []
+    for w in range(nw):
+        out += [peq[1, w] | peq[3, w], peq[2, w] | peq[3, w], peq[4, w]]
+    return out
 
 
 def myers_init_state(nw: int, groups: int, lanes: int) -> list:
@@ -401,7 +452,8 @@ def build_peq32(subjects: np.ndarray, nw: int) -> np.ndarray:
 def run_rows(body: Body, state: list, peq: np.ndarray, query: np.ndarray, groups: int = 1) -> None:
     code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
     nw = peq.shape[1]
+    planes = code_planes(peq)
     for ch in query:
         c = code.get(int(ch), 0)
         eq = [peq[c, w] for _ in range(groups) for w in range(nw)]
-        body.simulate(state, eq)
+        body.simulate(state, eq, cls=c, planes=planes)

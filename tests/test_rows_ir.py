@@ -39,6 +39,21 @@ def test_myers_body_matches_oracle(oracle, qlen, slen):
         assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
 
 
+@pytest.mark.parametrize("qlen,slen", [(300, 300), (150, 150), (90, 257)])
+def test_myers_planes_body_matches_oracle(oracle, qlen, slen):
+    q, s = _inputs(oracle, 1500 + slen, 2, 40, qlen, slen)
+    s[5, 3:9] = ord("N")
+    q[1, 4:8] = ord("N")
+    nw = (slen + 31) // 32
+    body = R.myers_planes_body(nw)
+    peq = R.build_peq32(s, nw)
+    want = oracle.myers64(q, s)
+    for i in range(q.shape[0]):
+        st = R.myers_init_state(nw, 1, s.shape[0])
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
+
+
 def test_myers_two_groups_per_wave(oracle):
     q, s = _inputs(oracle, 77, 2, 32, 150, 150)
     nw = 5
@@ -77,7 +92,7 @@ def test_bitpal_body_on_golden_specials(oracle):
 
 
 def test_emitted_asm_respects_the_vcc_hazard():
-    for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5)):
+    for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5), R.myers_planes_body(12)):
         lines = body.emit_asm(lambda name: name)
         since = 99
         for ln in lines:
