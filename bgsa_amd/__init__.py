@@ -31,6 +31,7 @@ def build_library(verbose: bool = False) -> Path:
     """Compile libbgsa_hip.so in-tree (hipcc --offload-arch=gfx950).  Works without a GPU."""
     out = None if verbose else subprocess.DEVNULL
     subprocess.run(["make", "-C", str(HERE / "csrc"), "-j8"], check=True, stdout=out)
+    subprocess.run(["make", "-C", str(HERE / "host")], check=True, stdout=out)  # aligner, convert (C)
     return LIB_PATH
 
 
@@ -68,6 +69,8 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_kernel_name.restype = ctypes.c_char_p
     L.bgsa_hip_malloc.argtypes = [ctypes.POINTER(vp), sz]
     L.bgsa_hip_free.argtypes = [vp]
+    L.bgsa_hip_malloc_host.argtypes = [ctypes.POINTER(vp), sz]
+    L.bgsa_hip_free_host.argtypes = [vp]
     L.bgsa_hip_memcpy_h2d.argtypes = [vp, vp, sz, vp]
     L.bgsa_hip_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     L.bgsa_hip_memset.argtypes = [vp, i32, sz, vp]

@@ -159,6 +159,17 @@ int bgsa_hip_free(void *dptr)
     BGSA_HIP_TRY(hipFree(dptr));
     return BGSA_HIP_OK;
 }
+int bgsa_hip_malloc_host(void **hptr, size_t bytes)
+{
+    if (!hptr) return BGSA_HIP_EINVAL;
+    BGSA_HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_free_host(void *hptr)
+{
+    BGSA_HIP_TRY(hipHostFree(hptr));
+    return BGSA_HIP_OK;
+}
 int bgsa_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
     BGSA_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));

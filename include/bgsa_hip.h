@@ -131,6 +131,9 @@ int bgsa_hip_set_device(int device);
 /* Plain device memory helpers so C hosts need no HIP headers. */
 int bgsa_hip_malloc(void **dptr, size_t bytes);
 int bgsa_hip_free(void *dptr);
+/* Page-locked host memory (full-rate asynchronous copies for the pipeline driver). */
+int bgsa_hip_malloc_host(void **hptr, size_t bytes);
+int bgsa_hip_free_host(void *hptr);
 int bgsa_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int bgsa_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int bgsa_hip_memset(void *dst, int value, size_t bytes, void *stream);

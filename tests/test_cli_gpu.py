@@ -1,0 +1,66 @@
+"""The `aligner` / `convert` command-line programs (bgsa_amd/host, plain C on the C ABI) against the
+golden fixtures: same files in, same `convert -r` text out as the reference's own binaries."""
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import bgsa_amd as B
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+HOST = Path(B.__file__).resolve().parent / "host"
+ROOT = HOST.parent.parent
+ALGO_FLAG = {"original_cpu": "myers", "original_avx2": "bitpal", "banded_cpu": "banded"}
+
+
+def _run_cli(tmp_path, g, bucket_bytes=None, converter=None):
+    (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
+    (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
+    cmd = [str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-f", "result.txt",
+           "-a", ALGO_FLAG[g["variant"]]]
+    if g["k"] >= 0:
+        cmd += ["-k", str(g["k"])]
+    env = dict(os.environ)
+    if bucket_bytes:
+        env["BGSA_READ_BUCKET_SIZE"] = str(bucket_bytes)
+    p = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "cal GCUPS is" in p.stdout and "Total GCUPS is" in p.stdout
+    conv = converter or (HOST / "convert")
+    subprocess.run([str(conv), "-r", "result.txt", "-o", "scores.txt"], cwd=tmp_path, check=True, capture_output=True)
+    flat = np.loadtxt(tmp_path / "scores.txt", dtype=np.int64, ndmin=1)
+    return flat.reshape(g["queries"].shape[0], g["subjects"].shape[0]), p.stdout
+
+
+@pytest.mark.parametrize("name", ["f1_myers_150", "f6_myers_ns100", "f2_myers_1000", "f7_bitpal_150", "f8_banded_k8_150",
+                                  "f9_myers_140x150"])
+def test_cli_matches_golden(tmp_path, name):
+    g = load_golden(name)
+    got, _ = _run_cli(tmp_path, g)
+    assert np.array_equal(got, g["scores"])
+
+
+def test_cli_many_read_buckets_and_query_blocks(tmp_path, oracle):
+    # 5 read buckets (the last one padded with 'N' reads) x 3 query blocks of REF_BUCKET_COUNT
+    q = oracle.gen_reads(91, 230, 150)
+    s = oracle.gen_reads(92, 300, 150)
+    g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
+    got, report = _run_cli(tmp_path, g, bucket_bytes=64 * 151 + 10)
+    assert np.array_equal(got, oracle.myers64(q, s))
+    assert "subject_count is 320" in report  # 300 reads + 20 padding reads, as the reference counts them
+    info = np.fromfile(tmp_path / "result.txt.info", dtype=np.uint8)
+    assert int(np.frombuffer(info[:4].tobytes(), dtype=np.int32)[0]) == 5
+
+
+def test_reference_convert_reads_our_result_files(tmp_path):
+    # the result / .info pair is the reference's format: its own `convert -r` must decode it
+    ref_convert = ROOT / "oracle" / "_ref" / "original_cpu" / "convert"
+    if not ref_convert.exists():
+        pytest.skip("reference binaries not built (oracle/_ref)")
+    g = load_golden("f1_myers_150")
+    got, _ = _run_cli(tmp_path, g, bucket_bytes=128 * 151, converter=ref_convert)
+    assert np.array_equal(got, g["scores"])
