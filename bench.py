@@ -150,7 +150,7 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run: RCCL even for one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 

@@ -20,9 +20,11 @@
 // test holds at that LAST checkpoint; any earlier test that fires implies it.  A wave therefore
 // tests every 16 rows from the start and stops as soon as all 64 lanes are past the limit.
 //
-// Band of 2k+1 (+1 carry) bits: 32-bit words for k <= 15, 64-bit words for k <= 31.
+// Band of 2k+1 (+1 carry) bits: 32-bit words for k <= 15, 64-bit words for k <= 31; any length.
 // Supported domain: query_len == subject_len (the reference's band is mis-aligned otherwise,
 // SURVEY.md §8(a) A5) — anything else is refused loudly.
+#include <stdlib.h>
+
 #include "bgsa_common.h"
 
 namespace bgsa {
@@ -61,54 +63,11 @@ __device__ __forceinline__ void band_row(T win, T &vp, T &vn, uint32_t &acc)
     acc += 1u - static_cast<uint32_t>(d0 & 1);
 }
 
-// Rows [WI*W, WI*W+W) of one query; recursion over WI keeps every M[][] index a constant.
-template <typename T, int NX, int WI>
-struct BandChunks {
-    static __device__ __forceinline__ void run(const T (&M)[kChars][NX], UniformBytes &qs, T &vp, T &vn,
-                                               uint32_t &acc, bool &dead, bool &all_dead, int len, int k,
-                                               T band_mask, uint32_t max_err, int last_check)
-    {
-        constexpr int W = BandWord<T>::bits;
-        if (!all_dead) {
-            for (int j = 0; j < W; j++) {
-                const int r = WI * W + j;
-                if (r >= len || all_dead) break;
-                if ((r & 3) == 0) qs.refill(r, len - r);
-                const uint32_t c = __builtin_amdgcn_readfirstlane(qs.next());
-                // (the per-case asm comments keep hipcc from folding the switch into a dynamically
-                // indexed load of M[c][WI], which would push M[][] into scratch memory)
-                T win;
-                switch (c) {
-                case 0: win = BandWord<T>::funnel(M[0][WI + 1], M[0][WI], j); asm volatile("; class 0" : "+v"(win)); break;
-                case 1: win = BandWord<T>::funnel(M[1][WI + 1], M[1][WI], j); asm volatile("; class 1" : "+v"(win)); break;
-                case 2: win = BandWord<T>::funnel(M[2][WI + 1], M[2][WI], j); asm volatile("; class 2" : "+v"(win)); break;
-                case 3: win = BandWord<T>::funnel(M[3][WI + 1], M[3][WI], j); asm volatile("; class 3" : "+v"(win)); break;
-                default: win = BandWord<T>::funnel(M[4][WI + 1], M[4][WI], j); asm volatile("; class 4" : "+v"(win)); break;
-                }
-                if (r == k) acc = 0;  // scoring starts at row k with err = k (:116-134)
-                band_row<T>(win & band_mask, vp, vn, acc);
-                const int done = r + 1;
-                if (done <= last_check && ((done & 15) == 0 || done == last_check)) {
-                    const bool over = done > k && (static_cast<uint32_t>(k) + acc > max_err);
-                    if (done == last_check) dead = over;
-                    if (__builtin_amdgcn_ballot_w64(!over) == 0) {  // every lane is past the limit
-                        dead = true;
-                        all_dead = true;
-                    }
-                }
-            }
-        }
-        BandChunks<T, NX, WI + 1>::run(M, qs, vp, vn, acc, dead, all_dead, len, k, band_mask, max_err, last_check);
-    }
-};
-template <typename T, int NX>
-struct BandChunks<T, NX, NX - 1> {
-    static __device__ __forceinline__ void run(const T (&)[kChars][NX], UniformBytes &, T &, T &, uint32_t &,
-                                               bool &, bool &, int, int, T, uint32_t, int) {}
-};
-
-// NX = words of Mext kept in registers per character class (incl. one zero spare for the funnel).
-template <typename T, int NX>
+// Only the first three Mext words per class are register-resident (they serve rows 0..2W-1, which
+// is as far as most waves get on unrelated reads); beyond that the wave re-reads, every W rows,
+// the word the next W windows straddle (5 coalesced loads that hit L1/L2), so the kernel needs
+// ~45 VGPRs at any length.
+template <typename T>
 __global__ __launch_bounds__(256) void banded_kernel(
     const char *__restrict__ content, const T *__restrict__ mext, int8_t *__restrict__ out,
     int len, long long ld, int n_groups, int word_num, int ref_start, int ref_end, int q_tile, int k)
@@ -117,13 +76,14 @@ __global__ __launch_bounds__(256) void banded_kernel(
     const int lane = threadIdx.x & (kLanes - 1);
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (group >= n_groups) return;
-
-    T M[kChars][NX];
     const T *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+
+    // Words 0..2 of every class stay in registers across the query tile (rows 0 .. 2W-1).
+    T first[kChars][3];
 #pragma unroll
     for (int c = 0; c < kChars; c++)
 #pragma unroll
-        for (int w = 0; w < NX; w++) M[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : T(0);
+        for (int w = 0; w < 3; w++) first[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : T(0);
 
     const int h = k;                       // h_threshold = k + n - m with n == m (:70)
     const int band_down = k + h;           // band_length - 1 (:71-72)
@@ -141,27 +101,155 @@ __global__ __launch_bounds__(256) void banded_kernel(
     for (int q = q0; q < q1; q++) {
         T vp = 0, vn = 0;                  // :96-97
         uint32_t acc = 0;                  // err - k; rows < k do not score (:116-123)
-        bool dead = false;
-        bool all_dead = false;
+        bool dead = false, all_dead = false;
         UniformBytes qs(content + static_cast<size_t>(q) * (len + 1));
-        // Rows wi*W .. wi*W+W-1 read the window from Mext words wi and wi+1: one statically
-        // indexed chunk per word so that M[][] stays in registers.
-        BandChunks<T, NX, 0>::run(M, qs, vp, vn, acc, dead, all_dead, len, k, band_mask, max_err, last_check);
-        // :230-245 — walk the last row across the band, keep the minimum.
-        uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
-        for (int i = 0; i <= h; i++) {
-            err += static_cast<uint32_t>((vp >> i) & 1);
-            err -= static_cast<uint32_t>((vn >> i) & 1);
-            best = err < best ? err : best;
+        T lo[kChars], hi[kChars];
+#pragma unroll
+        for (int c = 0; c < kChars; c++) hi[c] = first[c][0];
+        for (int r = 0; r < len && !all_dead; r++) {
+            const int j = r & (W - 1);
+            if (j == 0) {                  // windows of rows r .. r+W-1 straddle words r/W and r/W+1
+                const int wi = r / W;
+#pragma unroll
+                for (int c = 0; c < kChars; c++) {
+                    lo[c] = hi[c];
+                    if (wi == 0) hi[c] = first[c][1];          // resident: no memory latency on the
+                    else if (wi == 1) hi[c] = first[c][2];     // rows most waves ever reach
+                    else hi[c] = (wi + 1 < word_num) ? g[(c * word_num + wi + 1) * kLanes] : T(0);
+                }
+            }
+            if ((r & 3) == 0) qs.refill(r, len - r);
+            const uint32_t c = __builtin_amdgcn_readfirstlane(qs.next());
+            T win;
+            switch (c) {
+            case 0: win = BandWord<T>::funnel(hi[0], lo[0], j); break;
+            case 1: win = BandWord<T>::funnel(hi[1], lo[1], j); break;
+            case 2: win = BandWord<T>::funnel(hi[2], lo[2], j); break;
+            case 3: win = BandWord<T>::funnel(hi[3], lo[3], j); break;
+            default: win = BandWord<T>::funnel(hi[4], lo[4], j); break;
+            }
+            if (r == k) acc = 0;           // scoring starts at row k with err = k (:116-134)
+            band_row<T>(win & band_mask, vp, vn, acc);
+            const int done = r + 1;
+            if (done <= last_check && ((done & 15) == 0 || done == last_check)) {
+                const bool over = done > k && (static_cast<uint32_t>(k) + acc > max_err);
+                if (done == last_check) dead = over;
+                if (__builtin_amdgcn_ballot_w64(!over) == 0) {  // every lane is past the limit
+                    dead = true;
+                    all_dead = true;
+                }
+            }
         }
-        dst[static_cast<size_t>(q - ref_start) * ld] = dead ? static_cast<int8_t>(HIP_MAX_ERROR) : static_cast<int8_t>(best);
+        int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+        if (!all_dead) {
+            // :230-245 — walk the last row across the band, keep the minimum.
+            uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
+            for (int i = 0; i <= h; i++) {
+                err += static_cast<uint32_t>((vp >> i) & 1);
+                err -= static_cast<uint32_t>((vn >> i) & 1);
+                best = err < best ? err : best;
+            }
+            if (!dead) result = static_cast<int8_t>(best);
+        }
+        dst[static_cast<size_t>(q - ref_start) * ld] = result;
+    }
+}
+
+// ---- generated row loop (gen_rows_asm.py: gen_banded_function) -----------------------------------
+#include "banded_rows_gen.inc"
+
+// k <= 15: the whole query runs inside one generated asm block — 12 VALU + ~8 SALU per row, the
+// window advance / checkpoints / early exit driven by EVENT tokens of the packed stream
+// (bgsa_common.h: banded_stream_layout).  Same results as banded_kernel<uint32_t>.
+__global__ __launch_bounds__(256) void banded_asm_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
+    long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (group >= n_groups) return;
+    const uint32_t *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes;
+
+    uint32_t first[kChars][3];
+    unsigned long long base[kChars];
+#pragma unroll
+    for (int c = 0; c < kChars; c++) {
+        base[c] = uniform_u64(reinterpret_cast<unsigned long long>(g + static_cast<size_t>(c) * word_num * kLanes));
+#pragma unroll
+        for (int w = 0; w < 3; w++) first[c][w] = g[(c * word_num + w) * kLanes + lane];
+    }
+    const int h = k;
+    const uint32_t band_mask = (1u << (k + h + 1)) - 1u;   // 2k+1 <= 31 bits
+    const uint32_t limit = static_cast<uint32_t>(h + 1);   // err > k+h+1  <=>  errors since row k > h+1
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int8_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        uint32_t st[3] = {0u, 0u, 0u};
+        uint32_t M[kChars][3];
+#pragma unroll
+        for (int c = 0; c < kChars; c++)
+#pragma unroll
+            for (int w = 0; w < 3; w++) M[c][w] = first[c][w];
+        uint32_t voff = static_cast<uint32_t>(lane * 4 + 3 * kLanes * 4);  // word 3 of this lane
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        const unsigned long long dead_mask =
+            banded_rows_asm(st, M, voff, base, uniform_u64(s),
+                            __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2), band_mask, limit);
+        const bool dead = (dead_mask >> lane) & 1ull;
+        int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+        if (dead_mask != ~0ull) {
+            // :230-245 — walk the last row across the band, keep the minimum.
+            uint32_t err = static_cast<uint32_t>(k) + st[2], best = err;
+            for (int i = 0; i <= h; i++) {
+                err += (st[0] >> i) & 1u;
+                err -= (st[1] >> i) & 1u;
+                best = err < best ? err : best;
+            }
+            if (!dead) result = static_cast<int8_t>(best);
+        }
+        dst[static_cast<size_t>(q) * ld] = result;
     }
 }
 
 namespace {
 
-template <typename T, int NX>
-int launch_nx(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len,
+int banded_impl()
+{
+    static const int impl = [] {
+        const char *e = getenv("BGSA_BANDED_IMPL");
+        return (e && e[0] == 'c') ? 1 : 0;
+    }();
+    return impl;
+}
+
+int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len, int64_t read_count,
+               int ref_start, int ref_end, int word_num, int k, void *d_workspace, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    int q_tile = 32;
+    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("banded: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (int rc = launch_pack_banded(d_content, len, k, ref_start, ref_end, d_workspace, stream)) return rc;
+    const int stride = banded_stream_layout(len, k, nullptr, nullptr);
+    hipLaunchKernelGGL(banded_asm_kernel, grid, dim3(256), 0, stream, static_cast<const unsigned char *>(d_workspace),
+                       d_peq, d_results, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq,
+                       q_tile, k, stride);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+template <typename T>
+int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len,
               int64_t read_count, int ref_start, int ref_end, int word_num, int k, hipStream_t stream)
 {
     const int nq = ref_end - ref_start;
@@ -174,7 +262,7 @@ int launch_nx(const char *d_content, const uint32_t *d_peq, int8_t *d_results, i
         set_error_text("banded: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL((banded_kernel<T, NX>), grid, dim3(256), 0, stream, d_content,
+    hipLaunchKernelGGL((banded_kernel<T>), grid, dim3(256), 0, stream, d_content,
                        reinterpret_cast<const T *>(d_peq), d_results, len,
                        static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, ref_start,
                        ref_end, q_tile, k);
@@ -193,7 +281,7 @@ const char *banded_kernel_name(int word_num)
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, int k,
-                  hipStream_t stream)
+                  void *d_workspace, hipStream_t stream)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
     if (ref_len != read_len) {
@@ -204,19 +292,14 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
         set_error_text("banded: threshold must satisfy 1 <= k <= 31 and 2k+1 < length");
         return BGSA_HIP_EUNSUPPORTED;
     }
-#define BGSA_BANDED(T, NX)                                                                          \
-    if (word_num <= NX)                                                                             \
-        return launch_nx<T, NX>(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, \
-                                word_num, k, stream);
-    if (k <= 15) {
-        BGSA_BANDED(uint32_t, 4) BGSA_BANDED(uint32_t, 7) BGSA_BANDED(uint32_t, 10)
-        BGSA_BANDED(uint32_t, 18) BGSA_BANDED(uint32_t, 34)
-    } else {
-        BGSA_BANDED(uint64_t, 3) BGSA_BANDED(uint64_t, 5) BGSA_BANDED(uint64_t, 9) BGSA_BANDED(uint64_t, 18)
-    }
-#undef BGSA_BANDED
-    set_error_text("banded: subjects longer than ~1000 bp are not supported yet");
-    return BGSA_HIP_EUNSUPPORTED;
+    if (k <= 15 && banded_impl() == 0)
+        return launch_asm(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
+                          d_workspace, stream);
+    if (k <= 15)
+        return launch_t<uint32_t>(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end,
+                                  word_num, k, stream);
+    return launch_t<uint64_t>(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end,
+                              word_num, k, stream);
 }
 
 }  // namespace bgsa

@@ -42,9 +42,62 @@ inline size_t stream_stride(int ref_len) { return static_cast<size_t>(stream_win
 int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
                         void *d_streams, hipStream_t stream);
 
+// Banded stream (rows_ir.py:banded_tokens): row codes plus EVENT tokens {7, bits}: 1 = reset the
+// error count (row k), 2 = advance the match-string words (every 32 rows), 4 = test the limit on
+// all lanes, 8 = latch the reject mask (the reference's last checkpoint).  A two-byte token never
+// straddles a window: the window is closed early with a REFILL instead.  Writes the stream when
+// dst != nullptr (row = mapped query characters); returns its length in bytes including the
+// spare window.  The same routine sizes the workspace on the host and fills it on the device.
+__host__ __device__ inline int banded_stream_layout(int len, int k, const char *row, unsigned char *dst)
+{
+    const int last = (len <= 64) ? len : ((len - k > 64) ? len - k : 64);
+    int pos = 0, slot = 0, pending = 0;
+    auto put = [&](unsigned char b) {
+        if (dst) dst[pos] = b;
+        pos++;
+        if (++slot == 7) {
+            if (dst) dst[pos] = kCodeRefill;
+            pos++;
+            slot = 0;
+        }
+    };
+    auto put_event = [&](int bits) {
+        if (slot == 6) {  // one payload byte left: close the window
+            if (dst) { dst[pos] = kCodeRefill; dst[pos + 1] = kCodeEnd; }
+            pos += 2;
+            slot = 0;
+        }
+        put(7);
+        put(static_cast<unsigned char>(bits));
+    };
+    for (int r = 0; r < len; r++) {
+        if (r == k) pending |= 1;
+        if (r > 0 && (r & 31) == 0) pending |= 2;
+        if (pending) { put_event(pending); pending = 0; }
+        unsigned char code = 0;
+        if (row) { code = static_cast<unsigned char>(row[r]); if (code > 4) code = 0; }
+        put(code);
+        const int done = r + 1;
+        if (done > k && done <= last && ((done & 15) == 0 || done == last)) pending |= 4 | (done == last ? 8 : 0);
+    }
+    if (pending) put_event(pending);
+    put(kCodeEnd);
+    while (pos & 7) {  // pad the last window with END
+        if (dst) dst[pos] = kCodeEnd;
+        pos++;
+    }
+    for (int i = 0; i < 8; i++) {  // spare window: the loop fetches one window ahead
+        if (dst) dst[pos] = kCodeEnd;
+        pos++;
+    }
+    return pos;
+}
+int launch_pack_banded(const char *d_content, int len, int k, int ref_start, int ref_end, void *d_streams,
+                       hipStream_t stream);
+
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, int k,
-                  hipStream_t stream);
+                  void *d_workspace, hipStream_t stream);
 const char *banded_kernel_name(int word_num);
 
 int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,

@@ -121,7 +121,7 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k)
     case BGSA_ALGO_BANDED: {
         (void)query_len;                                     // equal lengths only (banded.hip)
         const int w = k <= 15 ? 32 : 64;                     // band of 2k+2 bits per word
-        return (subject_len + w - 1) / w + 1;                // + one zero word for the funnel shift
+        return (subject_len + w - 1) / w + 2;                // + zero words for the funnel shift / prefetch
     }
     default: return -1;
     }
@@ -215,8 +215,9 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream)
 
 size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int n_queries)
 {
-    (void)algo;
     if (ref_len <= 0 || n_queries <= 0) return 0;
+    if (algo == BGSA_ALGO_BANDED)  // event tokens make the stream longer; k = 1 is the longest
+        return static_cast<size_t>(banded_stream_layout(ref_len, 1, nullptr, nullptr) + 16) * n_queries;
     return stream_stride(ref_len) * static_cast<size_t>(n_queries);
 }
 
@@ -251,7 +252,7 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
                             read_count, ref_start, ref_end, word_num, d_workspace, s);
     case BGSA_ALGO_BANDED:
         return launch_banded(d_content, d_peq, static_cast<int8_t *>(d_results), ref_len, read_len,
-                             read_count, ref_start, ref_end, word_num, k, s);
+                             read_count, ref_start, ref_end, word_num, k, d_workspace, s);
     case BGSA_ALGO_BITPAL:
         if (word_num != (read_len + 31) / 32) {
             set_error_text("cal_align_score_dev: word_num does not match read_len for BitPAl");

@@ -140,6 +140,146 @@ __device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_
 """
 
 
+def gen_banded_function() -> str:
+    """Row loop of the banded kernel (32-bit band words, k <= 15).  Same threaded-code skeleton
+    plus stream code 7 = EVENT (followed by an argument byte): test/latch the reject mask, reset
+    the error count at row k, advance the match-string words every 32 rows (rows_ir.banded_tokens)."""
+    body = R.banded_body()
+    slot_of, n_slots = body.allocate_temps()
+    S_MASK, S_SH, S_ARG, S_THR = "s72", "s73", "s74", "s78"
+    S_DEAD, S_TMP = "s[76:77]", "s[90:91]"
+    S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
+    clobbers = CLOBBERS[:-3] + ["s72", "s73", "s74", "s76", "s77", "s78"] + [f"s{i}" for i in range(80, 92)] + \
+        ["vcc", "scc", "memory"]
+
+    def reg_for(c: int):
+        def reg(name: str) -> str:
+            if name.startswith("S"):
+                return f"%[s{name[1:]}]"
+            if name.startswith("E"):
+                return f"%[m{name[1:]}_{c}]"
+            if name == "$mask":
+                return S_MASK
+            if name == "$sh":
+                return S_SH
+            if name == "$one":
+                return "1"
+            return f"%[t{slot_of[name]}]"
+        return reg
+
+    def disp() -> list[str]:
+        return dispatch()
+
+    asm = [
+        f"s_mov_b64 {S_PTR}, %[qp]",
+        f"s_mov_b32 {S_LEFT}, %[nwin]",
+        f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+        f"s_mov_b32 {S_MASK}, %[mask]",
+        f"s_mov_b32 {S_THR}, %[thr]",
+        f"s_mov_b32 {S_SH}, 0",
+        f"s_mov_b64 {S_DEAD}, 0",
+    ]
+    asm += [f"s_mov_b64 {S_BASE[c]}, %[base{c}]" for c in range(5)]
+    asm += [
+        f"s_getpc_b64 {S_PC}",
+        "L_anchor_%=:",
+        f"s_add_u32 {S_BASE_LO}, {S_PC_LO}, (L_body0_%= - L_anchor_%=)",
+        f"s_addc_u32 {S_BASE_HI}, {S_PC_HI}, 0",
+        "s_waitcnt lgkmcnt(0)",
+    ]
+    asm += disp()
+    for c in range(5):
+        asm.append(f"L_body{c}_%=:")
+        asm += body.emit_asm(reg_for(c), c)
+        asm.append(f"s_add_u32 {S_SH}, {S_SH}, 1")
+        asm += disp()
+    asm.append("L_body5_%=:")  # END
+    asm.append("s_branch L_done_%=")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - 4) / 4, 4, 0xbf800000")
+    asm.append("L_body6_%=:")  # REFILL
+    asm += [
+        f"s_sub_u32 {S_LEFT}, {S_LEFT}, 1",
+        "s_cbranch_scc1 L_done_%=",
+        "s_waitcnt lgkmcnt(0)",
+        f"s_mov_b64 {S_WIN}, {S_NXT}",
+        f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 8",
+        f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+    ]
+    asm += disp()
+    asm.append("L_refill_end_%=:")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
+    asm.append("L_body7_%=:")  # EVENT <arg>
+    asm += [
+        f"s_and_b32 {S_ARG}, {S_WIN_LO}, 0xff",
+        f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
+        # bit 2: test err > limit on every lane; bit 3: latch the reject mask (last checkpoint)
+        f"s_bitcmp1_b32 {S_ARG}, 2",
+        "s_cbranch_scc0 L_ev_reset_%=",
+        f"v_cmp_lt_u32 vcc, {S_THR}, %[s2]",
+        f"s_bitcmp1_b32 {S_ARG}, 3",
+        "s_cbranch_scc0 L_ev_all_%=",
+        f"s_mov_b64 {S_DEAD}, vcc",
+        "L_ev_all_%=:",
+        f"s_xor_b64 {S_TMP}, vcc, exec",
+        "s_cbranch_scc1 L_ev_reset_%=",
+        f"s_mov_b64 {S_DEAD}, exec",       # every lane is past the limit: the wave is done
+        "s_branch L_done_%=",
+        "L_ev_reset_%=:",
+        f"s_bitcmp1_b32 {S_ARG}, 0",      # bit 0: scoring starts (row k)
+        "s_cbranch_scc0 L_ev_adv_%=",
+        "v_mov_b32 %[s2], 0",
+        "L_ev_adv_%=:",
+        f"s_bitcmp1_b32 {S_ARG}, 1",      # bit 1: next 32 rows -> shift the match-string words down
+        "s_cbranch_scc0 L_ev_out_%=",
+        "s_waitcnt vmcnt(0)",
+    ]
+    for c in range(5):
+        asm += [f"v_mov_b32 %[m0_{c}], %[m1_{c}]", f"v_mov_b32 %[m1_{c}], %[m2_{c}]"]
+    for c in range(5):
+        asm.append(f"global_load_dword %[m2_{c}], %[voff], {S_BASE[c]}")
+    asm += [
+        "v_add_u32 %[voff], 0x100, %[voff]",
+        f"s_mov_b32 {S_SH}, 0",
+        "L_ev_out_%=:",
+    ]
+    asm += disp()
+    asm.append("L_done_%=:")
+    asm.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    asm.append(f"s_mov_b64 %[dead], {S_DEAD}")
+
+    text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(3)]
+    outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(3)]
+    outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)']
+    outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
+    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[mask] "s"(band_mask)', '[thr] "s"(limit)']
+    ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
+    clob = ", ".join(f'"{x}"' for x in clobbers)
+    return f"""
+// {body.valu_count()} VALU per row ({sum(op.kind in ('lshr1', 'alignbit') for op in body.ops)} of them slow-class), {n_slots} temporaries
+// state = {{VP, VN, errors since row k}}; M[c][0..2] = three consecutive words of class c's offset
+// match string (word 2 is the prefetch target); voff = byte offset of the next word to fetch
+// relative to base[c]; returns the reject mask (lanes whose error count passed `limit` at the last
+// checkpoint, or all lanes if the wave stopped early).
+__device__ __forceinline__ unsigned long long banded_rows_asm(uint32_t (&state)[3], uint32_t (&M)[5][3], uint32_t &voff,
+                                                              const unsigned long long (&base)[5],
+                                                              const unsigned long long stream, const int n_windows,
+                                                              const uint32_t band_mask, const uint32_t limit)
+{{
+    uint32_t tmp[{max(n_slots, 1)}];
+    unsigned long long dead;
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+    return dead;
+}}
+"""
+
+
 def main() -> int:
     here = Path(__file__).resolve().parent
     head = "// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n"
@@ -176,6 +316,8 @@ def main() -> int:
     for nw in BITPAL_NW:
         parts.append(gen_function("bitpal_rows_asm", f"{nw}", R.bitpal_body(nw), 5 * nw, nw))
     (here / "bitpal_rows_gen.inc").write_text("".join(parts))
+    # ---- banded -------------------------------------------------------------------------------
+    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function())
     return 0
 
 

@@ -69,6 +69,10 @@ class Body:
     def ADDC(self, d, a, b): return self._emit("addc", d, a, b)       # d = a + b + VCC, VCC = carry out
     def SETC1(self): return self._emit("setc1", "")                    # VCC = all ones (carry-in 1)
 
+    def ADD(self, d, a, b): return self._emit("add", d, a, b)          # d = a + b, no carry
+    def LSHR1(self, d, a): return self._emit("lshr1", d, a)            # d = a >> 1 (slow class)
+    def ALIGNBIT(self, d, hi, lo, sh): return self._emit("alignbit", d, hi, lo, sh)  # ({hi,lo} >> sh)[31:0], sh scalar
+
     def MATCH3(self, d, b0, b1, b2):
         """d = columns whose 3-bit character code (b2 b1 b0) equals the row's class (0..4 = A C G T
         N): a v_bitop3 whose truth table depends on which of the five body copies it sits in."""
@@ -81,7 +85,7 @@ class Body:
         seen = []
         for op in self.ops:
             for r in (op.dst,) + op.srcs:
-                if r and not r.startswith(("S", "E", "B")) and r not in seen:
+                if r and not r.startswith(("S", "E", "B", "$")) and r not in seen:
                     seen.append(r)
         return seen
 
@@ -90,7 +94,7 @@ class Body:
         last_use = {}
         for i, op in enumerate(self.ops):
             for r in (op.dst,) + op.srcs:
-                if r and not r.startswith(("S", "E", "B")):
+                if r and not r.startswith(("S", "E", "B", "$")):
                     last_use[r] = i
         slot_of, free, n_slots = {}, [], 0
         for i, op in enumerate(self.ops):
@@ -100,7 +104,7 @@ class Body:
             for r in dying:
                 free.append(slot_of[r])
             d = op.dst
-            if d and not d.startswith(("S", "E", "B")) and d not in slot_of:
+            if d and not d.startswith(("S", "E", "B", "$")) and d not in slot_of:
                 if free:
                     slot_of[d] = free.pop()
                 else:
@@ -114,7 +118,8 @@ class Body:
         return sum(op.kind != "setc1" for op in self.ops)
 
     # ---- numpy interpreter --------------------------------------------------------------------
-    def simulate(self, state: list, eq: list, cls: int = 0, planes: list | None = None) -> None:
+    def simulate(self, state: list, eq: list, cls: int = 0, planes: list | None = None,
+                 scalars: dict | None = None) -> None:
         """state: list of uint32 arrays (updated in place); eq: match masks of the row's class
         ('E' registers); planes: the class-independent 'B' registers; cls: the row's class."""
         regs: dict[str, np.ndarray] = {}
@@ -127,6 +132,8 @@ class Body:
                 return eq[int(name[1:])]
             if name.startswith("B"):
                 return planes[int(name[1:])]
+            if name.startswith("$"):
+                return np.full_like(state[0], scalars[name])
             return regs[name]
 
         def wr(name, val):
@@ -148,6 +155,11 @@ class Body:
             elif k == "xor": wr(op.dst, s[0] ^ s[1])
             elif k == "not": wr(op.dst, s[0] ^ FULL)
             elif k == "mov": wr(op.dst, s[0])
+            elif k == "add": wr(op.dst, (s[0].astype(np.uint64) + s[1].astype(np.uint64)) & np.uint64(0xFFFFFFFF))
+            elif k == "lshr1": wr(op.dst, s[0] >> np.uint32(1))
+            elif k == "alignbit":
+                pair = (s[0].astype(np.uint64) << np.uint64(32)) | s[1].astype(np.uint64)
+                wr(op.dst, (pair >> s[2].astype(np.uint64)) & np.uint64(0xFFFFFFFF))
             elif k in ("bitop3", "match3"):
                 a, b, c = s
                 imm = op.imm if k == "bitop3" else op.imm[cls]
@@ -190,6 +202,9 @@ class Body:
             elif k == "xor": lines.append(f"v_xor_b32 {d}, {r[0]}, {r[1]}")
             elif k == "not": lines.append(f"v_not_b32 {d}, {r[0]}")
             elif k == "mov": lines.append(f"v_mov_b32 {d}, {r[0]}")
+            elif k == "add": lines.append(f"v_add_u32 {d}, {r[0]}, {r[1]}")
+            elif k == "lshr1": lines.append(f"v_lshrrev_b32 {d}, 1, {r[0]}")
+            elif k == "alignbit": lines.append(f"v_alignbit_b32 {d}, {r[0]}, {r[1]}, {r[2]}")
             elif k == "bitop3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm:02x}")
             elif k == "match3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm[cls]:02x}")
             elif k == "add_co": lines.append(f"v_add_co_u32 {d}, vcc, {r[0]}, {r[1]}")
@@ -290,6 +305,111 @@ def myers_score(state: list, nw: int, qlen: int, slen: int, group: int = 0) -> n
         score += np.bitwise_count(state[(group * nw + w) * 2] & mask).astype(np.int64)
         score -= np.bitwise_count(state[(group * nw + w) * 2 + 1] & mask).astype(np.int64)
     return (-score).astype(np.int16)
+
+
+# =================================================================================================
+# Banded Myers (reference banded/BGSA_CPU/align_core.c:19-67, one row of cpu_cal_D0 + cpu_cal_score)
+# =================================================================================================
+
+def banded_body() -> Body:
+    """32-bit band word (k <= 15).  State: S0 = VP, S1 = VN, S2 = errors counted on the lowest
+    diagonal since row k.  E0, E1 = the two words of the row's class match string (offset by k+1
+    bits) that the window straddles; scalars: $sh = row mod 32, $mask = band mask, $one = 1.
+
+    The window is one funnel shift of the match string by the row number — the reference shifts
+    five windows and feeds each a bit, every row (align_core.c:35-62).  Two slow-class
+    instructions remain (the funnel shift and D0 >> 1); everything else is fast class.
+    """
+    b = Body()
+    b.ALIGNBIT("w", "E1", "E0", "$sh")
+    b.BITOP3("x", "w", "$mask", "S1", lambda w, m, vn: (w & m) | vn)
+    b.AND("t", "x", "S0")
+    b.ADD("t", "t", "S0")
+    b.BITOP3("d0", "t", "S0", "x", lambda t, vp, x: (t ^ vp) | x)
+    b.BITOP3("hp", "d0", "S0", "S1", lambda d, vp, vn: ~(d | vp) | vn)
+    b.AND("hn", "d0", "S0")
+    b.LSHR1("x2", "d0")
+    b.AND("S1", "x2", "hp")
+    b.BITOP3("S0", "hp", "x2", "hn", lambda hp, x2, hn: ~(hp | x2) | hn)
+    b.BITOP3("e", "d0", "$one", "$one", lambda d, one, _o: ~d & one)
+    b.ADD("S2", "S2", "e")
+    return b
+
+
+def banded_last_check(length: int, k: int) -> int:
+    """Rows after which the reference runs its last err > max_err test (banded.hip)."""
+    h = k
+    return length if length <= 64 else max(64, length - h)
+
+
+def banded_tokens(length: int, k: int, word_bits: int = 32):
+    """The per-query token sequence of the banded stream, query characters as ('row', r):
+    ('event', bits) with bits 1 = reset the error count (row k), 2 = advance the match-string
+    words (every word_bits rows), 4 = test err > limit on all lanes, 8 = latch the reject mask
+    (the reference's last checkpoint).  Mirrors banded_stream_layout() in preprocess.hip."""
+    last = banded_last_check(length, k)
+    out, pending = [], 0
+    for r in range(length):
+        if r == k:
+            pending |= 1
+        if r > 0 and r % word_bits == 0:
+            pending |= 2
+        if pending:
+            out.append(("event", pending))
+            pending = 0
+        out.append(("row", r))
+        done = r + 1
+        if done > k and done <= last and (done % 16 == 0 or done == last):
+            pending |= 4 | (8 if done == last else 0)
+    if pending:
+        out.append(("event", pending))
+    return out
+
+
+def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int) -> np.ndarray:
+    """Whole banded pipeline on the CPU with the shipped row body: Mext preprocess, token
+    stream, events, final band walk.  Returns int8 results like the kernel."""
+    n, length = subjects.shape
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, c in zip(b"ACGTN", range(5)):
+        code[ch] = c
+    mapped = code[subjects]
+    nwords = (length + 31) // 32 + 2
+    mext = np.zeros((5, nwords, n), dtype=np.uint32)
+    for p in range(length):
+        i = p + k + 1
+        for c in range(5):
+            mext[c, i // 32] |= (mapped[:, p] == c).astype(np.uint32) << np.uint32(i % 32)
+    h = k
+    band_mask = np.uint32((1 << (2 * k + 1)) - 1)
+    body = banded_body()
+    st = [np.zeros(n, dtype=np.uint32) for _ in range(3)]
+    dead = np.zeros(n, dtype=bool)
+    wi, sh = 0, 0
+    qcode = code[query]
+    for kind, val in banded_tokens(length, k):
+        if kind == "event":
+            if val & 4:
+                over = st[2] > np.uint32(h + 1)
+                if val & 8:
+                    dead = over.copy()
+                if over.all():
+                    dead[:] = True
+                    break
+            if val & 1:
+                st[2] = np.zeros(n, dtype=np.uint32)
+            if val & 2:
+                wi, sh = wi + 1, 0
+        else:
+            c = int(qcode[val])
+            body.simulate(st, [mext[c, wi], mext[c, wi + 1]], scalars={"$sh": sh, "$mask": band_mask, "$one": 1})
+            sh += 1
+    err = st[2].astype(np.int64) + k
+    best = err.copy()
+    for i in range(h + 1):
+        err = err + ((st[0] >> np.uint32(i)) & 1) - ((st[1] >> np.uint32(i)) & 1)
+        best = np.minimum(best, err)
+    return np.where(dead, 127, best).astype(np.int8)
 
 
 # =================================================================================================

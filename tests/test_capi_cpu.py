@@ -43,8 +43,8 @@ def test_word_num(L):
     assert B.word_num(B.ALGO_MYERS, 150, 150) == 5
     assert B.word_num(B.ALGO_MYERS, 1000, 1000) == 32
     assert B.word_num(B.ALGO_MYERS, 1, 32) == 1 and B.word_num(B.ALGO_MYERS, 1, 33) == 2
-    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 6   # 32-bit words of the offset match string + spare
-    assert B.word_num(B.ALGO_BANDED, 150, 150, 16) == 4  # 64-bit words above k = 15
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 7   # 32-bit words of the offset match string + 2 spare
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 16) == 5  # 64-bit words above k = 15
     assert B.group_words(B.ALGO_MYERS, 5) == 5 * 5 * 64
     assert B.group_words(B.ALGO_BANDED, 6, 8) == 5 * 6 * 64
     assert B.group_words(B.ALGO_BANDED, 4, 16) == 2 * 5 * 4 * 64
@@ -96,7 +96,7 @@ def test_host_handle_reads_layout_banded(L, oracle):
     rows = oracle.gen_reads(78, 64, 150)
     for k, dtype, W in ((8, np.uint32, 32), (16, np.uint64, 64)):
         padded, peq, wn = _host_preprocess(L, B.ALGO_BANDED, rows, k=k)
-        assert wn == (150 + W - 1) // W + 1
+        assert wn == (150 + W - 1) // W + 2
         peq = peq.view(dtype).reshape(-1, 5, wn, 64)
         s = 5
         for p in range(150):

@@ -68,7 +68,7 @@ def test_bitpal_lengths_vs_oracle(oracle, slen):
 
 
 @pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (150, 15), (150, 16), (150, 31), (64, 8), (65, 8), (73, 8),
-                                      (100, 12), (128, 8), (136, 8), (200, 8), (250, 20), (500, 8), (1000, 8)])
+                                      (100, 12), (128, 8), (136, 8), (200, 8), (250, 20), (500, 8), (1000, 8), (2000, 8), (1500, 25)])
 def test_banded_vs_oracle(oracle, length, k):
     # includes lengths (65, 136, 200) where the reference itself writes out of bounds: the oracle
     # (and the kernel) follow the in-bounds semantics there (DESIGN.md "banded domain")

@@ -91,6 +91,16 @@ def test_bitpal_body_on_golden_specials(oracle):
         assert np.array_equal(R.bitpal_score(st, nw, 150, 150), g["scores"][i])
 
 
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (150, 15), (64, 8), (65, 8), (100, 12), (200, 8)])
+def test_banded_body_and_events_match_oracle(oracle, length, k):
+    q = oracle.gen_reads(2500 + length + k, 4, length)
+    s = oracle.gen_reads(2600 + length + k, 96, length)
+    s[:48] = oracle.mutate(q[np.arange(48) % 4], np.arange(48) % (2 * k + 6), length + k)
+    want = oracle.banded64(q, s, k)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.banded_simulate(s, q[i], k), want[i])
+
+
 def test_emitted_asm_respects_the_vcc_hazard():
     for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5), R.myers_planes_body(12)):
         lines = body.emit_asm(lambda name: name)
