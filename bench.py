@@ -72,7 +72,8 @@ def issued_valu_per_row(algo: int, wn: int):
     if algo == B.ALGO_MYERS and wn <= 8:
         return R.myers_body(wn).valu_count()
     if algo == B.ALGO_MYERS and wn <= 32:
-        return None
+        nw = next(n for n in (12, 16, 20, 24, 28, 32) if n >= wn)
+        return R.myers_planes_body(nw).valu_count()
     if algo == B.ALGO_BITPAL and wn <= 8:
         return R.bitpal_body(wn).valu_count()
     return None

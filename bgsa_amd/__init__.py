@@ -63,7 +63,7 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_handle_reads_dev.argtypes = [i32, vp, i64, i32, i64, i32, i32, vp, vp]
     L.bgsa_hip_map_queries_dev.argtypes = [vp, i64, vp]
     L.bgsa_hip_cal_align_score_dev.argtypes = [i32, vp, vp, vp, i32, i32, i64, i32, i32, i32, i32, vp, sz, vp]
-    L.bgsa_hip_workspace_bytes.argtypes = [i32, i32, i32]
+    L.bgsa_hip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.bgsa_hip_workspace_bytes.restype = sz
     L.bgsa_hip_kernel_name.argtypes = [i32, i32]
     L.bgsa_hip_kernel_name.restype = ctypes.c_char_p
@@ -196,7 +196,7 @@ class DeviceAligner:
         ref_end = self.nq if ref_end is None else ref_end
         if out is None:
             out = torch.empty((ref_end - ref_start, self.ns), dtype=self.out_dtype, device=self.device)
-        need = int(lib().bgsa_hip_workspace_bytes(self.algo, self.qlen, ref_end - ref_start))
+        need = int(lib().bgsa_hip_workspace_bytes(self.algo, self.qlen, self.slen, ref_end - ref_start))
         if getattr(self, "d_work", None) is None or self.d_work.numel() < need:
             self.d_work = torch.empty(max(need, 8), dtype=torch.uint8, device=self.device)
         check(lib().bgsa_hip_cal_align_score_dev(self.algo, self.d_content.data_ptr(), self.d_peq.data_ptr(),

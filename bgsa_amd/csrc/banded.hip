@@ -155,6 +155,8 @@ __global__ __launch_bounds__(256) void banded_kernel(
     }
 }
 
+namespace { int banded_impl(); }
+
 // ---- generated row loop (gen_rows_asm.py: gen_banded_function) -----------------------------------
 #include "banded_rows_gen.inc"
 
@@ -274,9 +276,9 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
 
 const char *banded_kernel_name(int word_num)
 {
-    static thread_local char name[64];
-    snprintf(name, sizeof name, "banded_kernel<%d words>", word_num);
-    return name;
+    (void)word_num;
+    // k <= 15 -> banded_asm_kernel unless BGSA_BANDED_IMPL=c; the C ABI passes word_num only
+    return (threshold <= 15 && banded_impl() == 0) ? "banded_asm_kernel" : "banded_kernel<T>";
 }
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,

@@ -105,6 +105,16 @@ int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                   void *d_workspace, hipStream_t stream);
 const char *bitpal_kernel_name(int word_num);
 
+// long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.
+inline bool needs_long_kernel(int algo, int word_num)
+{
+    return (algo == BGSA_ALGO_MYERS && word_num > kMaxWords) || (algo == BGSA_ALGO_BITPAL && word_num > 8);
+}
+size_t long_state_bytes(int algo, int word_num);
+int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+                int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, void *d_state,
+                hipStream_t stream);
+
 int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
                       int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream);
 int launch_map_queries(char *d_content, int64_t bytes, hipStream_t stream);

@@ -94,6 +94,7 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
 const char *bitpal_kernel_name(int word_num)
 {
     static thread_local char name[64];
+    if (needs_long_kernel(BGSA_ALGO_BITPAL, word_num)) return "bitpal_long_kernel";
     snprintf(name, sizeof name, "bitpal_asm_kernel<%d>", word_num);
     return name;
 }
@@ -103,6 +104,9 @@ int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                   void *d_workspace, hipStream_t stream)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
+    if (needs_long_kernel(BGSA_ALGO_BITPAL, word_num))
+        return launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
+                           ref_end, word_num, d_workspace, stream);
     switch (word_num) {
 #define BGSA_CASE(N)                                                                            \
     case N:                                                                                     \
@@ -112,7 +116,7 @@ int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
         BGSA_CASE(7) BGSA_CASE(8)
 #undef BGSA_CASE
     default:
-        set_error_text("bitpal: subjects longer than 256 bp are not supported yet");
+        set_error_text("bitpal: no kernel for this word count");
         return BGSA_HIP_EUNSUPPORTED;
     }
 }

@@ -213,9 +213,10 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream)
     return launch_map_queries(d_content, bytes, static_cast<hipStream_t>(stream));
 }
 
-size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int n_queries)
+size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries)
 {
     if (ref_len <= 0 || n_queries <= 0) return 0;
+    if (read_len > 0 && needs_long_kernel(algo, (read_len + 31) / 32)) return long_state_bytes(algo, (read_len + 31) / 32);
     if (algo == BGSA_ALGO_BANDED)  // event tokens make the stream longer; k = 1 is the longest
         return static_cast<size_t>(banded_stream_layout(ref_len, 1, nullptr, nullptr) + 16) * n_queries;
     return stream_stride(ref_len) * static_cast<size_t>(n_queries);
@@ -232,7 +233,7 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         return BGSA_HIP_EINVAL;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t need = bgsa_hip_workspace_bytes(algo, ref_len, ref_end - ref_start);
+    const size_t need = bgsa_hip_workspace_bytes(algo, ref_len, read_len, ref_end - ref_start);
     if (d_workspace) {
         if (workspace_bytes < need) {
             set_error_text("cal_align_score_dev: workspace smaller than bgsa_hip_workspace_bytes()");

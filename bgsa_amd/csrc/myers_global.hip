@@ -347,7 +347,7 @@ const char *myers_kernel_name(int word_num)
 {
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
-    if (nw < 0) return "myers_global_kernel<unsupported>";
+    if (nw < 0) return "myers_long_kernel";
     if (myers_impl() == 0 && word_num > 8 && pick_planes_nw(word_num) > 0)
         snprintf(name, sizeof name, "myers_global_planes_kernel<%d>", pick_planes_nw(word_num));
     else
@@ -360,6 +360,9 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
                  void *d_workspace, hipStream_t stream)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
+    if (needs_long_kernel(BGSA_ALGO_MYERS, word_num))
+        return launch_long(BGSA_ALGO_MYERS, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
+                           ref_end, word_num, d_workspace, stream);
     if (myers_impl() == 0) {
         switch (pick_nw(word_num)) {
 #define BGSA_ASM_CASE(N)                                                                        \
@@ -392,7 +395,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         BGSA_CASE(20) BGSA_CASE(24) BGSA_CASE(28) BGSA_CASE(32)
 #undef BGSA_CASE
     default:
-        set_error_text("myers: subjects longer than 1024 bp are not supported yet");
+        set_error_text("myers: no kernel for this word count");
         return BGSA_HIP_EUNSUPPORTED;
     }
 }

@@ -212,7 +212,7 @@ int main(int argc, char **argv)
     const size_t rows_bytes = (size_t)(max_reads * row);
     const size_t peq_bytes = bgsa_hip_group_words(algo, word_num, threshold) * sizeof(hip_read_t) * (size_t)(max_reads / HIP_V_NUM);
     const size_t block_bytes = (size_t)REF_BUCKET_COUNT * (size_t)max_reads * esz;
-    const size_t work_bytes = bgsa_hip_workspace_bytes(algo, ref_len, REF_BUCKET_COUNT);
+    const size_t work_bytes = bgsa_hip_workspace_bytes(algo, ref_len, read_len, REF_BUCKET_COUNT);
 
     void *h_rows, *d_rows, *d_peq, *d_q, *d_out, *d_work;
     CK(bgsa_hip_malloc_host(&h_rows, rows_bytes));

@@ -150,14 +150,16 @@ int bgsa_hip_handle_reads_dev(int algo, const char *d_rows, int64_t avail_bytes,
  * (reference original/BGSA_CPU/file.c:134-139). */
 int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream);
 
-/* Scratch the hot path needs for n_queries queries of ref_len characters (the queries are
- * re-packed into an 8-byte-aligned code stream the kernels fetch through the scalar cache). */
-size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int n_queries);
+/* Scratch the hot path needs for n_queries queries of ref_len characters against subjects of
+ * read_len characters: the queries re-packed into 8-byte-aligned code streams the kernels fetch
+ * through the scalar cache, or, for subjects too long for the register-resident kernels (Myers
+ * > 1024 bp, BitPAl > 256 bp), the per-wave DP state. */
+size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries);
 
 /* The hot path.  d_content = mapped query rows, stride ref_len+1 (reference cal_cpu.c:78);
  * d_peq = Peq blocks of read_count subjects; d_results = [ref_end-ref_start][read_count]
  * (int16, or int8 for banded).  d_workspace = caller-owned device scratch of at least
- * bgsa_hip_workspace_bytes(algo, ref_len, ref_end-ref_start) bytes, or NULL to let the library
+ * bgsa_hip_workspace_bytes(algo, ref_len, read_len, ref_end-ref_start) bytes, or NULL to let the library
  * keep a grow-only scratch of its own (allocates on first use: not graph-capture safe).
  * All pointers are device pointers; asynchronous on `stream`. */
 int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read_t *d_peq,

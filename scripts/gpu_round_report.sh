@@ -1,0 +1,17 @@
+#!/bin/bash
+# Full GPU record for profiles/: tests, the four BASELINE configs with CPU baselines, rocprofv3 stats.
+# Run on the GPU box from the repo root:  bash scripts/gpu_round_report.sh <tag>
+tag=${1:-r01_final}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 500 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/summary.txt
+timeout -k 10 400 python bench.py --config 2 > $out/bench_cfg2.json 2> $out/bench_cfg2.err; echo "cfg2 rc=$?" | tee -a $out/summary.txt
+timeout -k 10 400 python bench.py --config 3 --cpu-sample 2000x100000 > $out/bench_cfg3.json 2> $out/bench_cfg3.err; echo "cfg3 rc=$?" | tee -a $out/summary.txt
+timeout -k 10 500 python bench.py --config 4 --cpu-sample 1000x50000 > $out/bench_cfg4.json 2> $out/bench_cfg4.err; echo "cfg4 rc=$?" | tee -a $out/summary.txt
+timeout -k 10 400 python bench.py --config 5 --cpu-sample 200x20000 > $out/bench_cfg5.json 2> $out/bench_cfg5.err; echo "cfg5 rc=$?" | tee -a $out/summary.txt
+for c in 2 3 4 5; do
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $out/prof_cfg$c.log 2>&1
+  echo "prof cfg$c rc=$?" | tee -a $out/summary.txt
+done
+tail -c 300 $out/pytest_gpu.log

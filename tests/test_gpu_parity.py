@@ -86,12 +86,18 @@ def test_banded_refuses_unequal_lengths(oracle):
         B.align_all_pairs(oracle.gen_reads(1, 2, 140), oracle.gen_reads(2, 64, 150), algo=B.ALGO_BANDED, k=8)
 
 
-def test_unsupported_lengths_fail_loudly(oracle):
-    q = oracle.gen_reads(1, 2, 64)
-    with pytest.raises(B.BgsaHipError):
-        B.align_all_pairs(q, oracle.gen_reads(2, 64, 1025), algo=B.ALGO_MYERS)
-    with pytest.raises(B.BgsaHipError):
-        B.align_all_pairs(q, oracle.gen_reads(2, 64, 257), algo=B.ALGO_BITPAL)
+@pytest.mark.parametrize("algo,qlen,slen", [(B.ALGO_MYERS, 1025, 1025), (B.ALGO_MYERS, 300, 2500), (B.ALGO_MYERS, 4000, 4000),
+                                            (B.ALGO_BITPAL, 257, 257), (B.ALGO_BITPAL, 500, 1000), (B.ALGO_BITPAL, 90, 300)])
+def test_beyond_register_limits_state_in_memory(oracle, algo, qlen, slen):
+    # Myers > 1024 bp and BitPAl > 256 bp run the state-in-memory kernels (long_kernels.hip)
+    q = oracle.gen_reads(8000 + qlen, 3, qlen)
+    s = oracle.gen_reads(9000 + slen, 130, slen)
+    m = min(qlen, slen)
+    s[:12, :m] = oracle.mutate(q[np.arange(12) % 3][:, :m], np.arange(12) * 7, slen)
+    s[3, 5:40] = ord("N")
+    got = B.align_all_pairs(q, s, algo=algo)
+    want = oracle.myers64(q, s) if algo == B.ALGO_MYERS else oracle.bitpal(q, s)
+    assert np.array_equal(got, want)
 
 
 def test_bad_arguments_fail_loudly():
