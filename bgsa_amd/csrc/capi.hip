@@ -227,6 +227,8 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
                                  int ref_start, int ref_end, int word_num, int k,
                                  void *d_workspace, size_t workspace_bytes, void *stream)
 {
+    if (ref_start >= 0 && ref_end >= ref_start && read_count >= 0 && (ref_end == ref_start || read_count == 0))
+        return BGSA_HIP_OK;  // an empty query window or an empty bucket: nothing to score
     if (!d_content || !d_peq || !d_results || ref_len <= 0 || read_len <= 0 || read_count < 0 ||
         (read_count % HIP_V_NUM) != 0 || ref_start < 0 || ref_end < ref_start || word_num <= 0) {
         set_error_text("cal_align_score_dev: bad argument (read_count must be a multiple of 64)");

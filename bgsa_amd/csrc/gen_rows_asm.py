@@ -293,10 +293,8 @@ def main() -> int:
              "__device__ __forceinline__ void myers_rows_asm(uint32_t (&state)[2 * G * NW],\n"
              "                                               const uint32_t (&P)[5][G * NW],\n"
              "                                               const unsigned long long stream, const int n_windows);\n"]
-    for nw in MYERS_NW:
-        for g in (1, 2):
-            if nw * g <= 10:
-                parts.append(gen_function("myers_rows_asm", f"{nw}, {g}", R.myers_body(nw, g), 2 * nw * g, nw * g))
+    for nw in MYERS_NW:  # G = 1 only: two groups per wave measured slower (fewer waves per SIMD)
+        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_body(nw, 1), 2 * nw, nw))
     parts.append("\n// Long subjects (NW 9..32): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ void myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"

@@ -100,6 +100,90 @@ def test_beyond_register_limits_state_in_memory(oracle, algo, qlen, slen):
     assert np.array_equal(got, want)
 
 
+def test_empty_inputs_are_no_ops(oracle):
+    # zero queries in the window / zero subjects: nothing to launch, nothing touched
+    L = B.lib()
+    q = oracle.gen_reads(5, 4, 50)
+    a = B.DeviceAligner(B.ALGO_MYERS)
+    a.set_queries(q)
+    a.set_subjects(oracle.gen_reads(6, 64, 50))
+    out = a.score(2, 2)
+    assert tuple(out.shape) == (0, 64)
+    import torch
+    sentinel = torch.full((4, 64), 7, dtype=torch.int16, device="cuda:0")
+    rc = L.bgsa_hip_cal_align_score_dev(B.ALGO_MYERS, a.d_content.data_ptr(), a.d_peq.data_ptr(), sentinel.data_ptr(),
+                                        50, 50, 0, 0, 4, 2, 0, None, 0, None)
+    assert rc == 0 and bool((sentinel == 7).all())
+
+
+def test_launch_is_graph_capturable(oracle):
+    """With a caller-owned workspace the hot path allocates nothing and never synchronises, so the
+    pack + score launches can be captured into a hipGraph and replayed."""
+    import torch
+    q = oracle.gen_reads(71, 40, 150)
+    s = oracle.gen_reads(72, 256, 150)
+    want = oracle.myers64(q, s)
+    a = B.DeviceAligner(B.ALGO_MYERS)
+    a.set_queries(q)
+    a.set_subjects(s)
+    out = torch.zeros((40, 256), dtype=torch.int16, device="cuda:0")
+    a.score(out=out)  # warm-up allocates the workspace outside the capture
+    torch.cuda.synchronize()
+    out.zero_()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            a.score(out=out)
+    torch.cuda.synchronize()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_large_batch_properties(oracle):
+    """A batch too large for the CPU oracle (2k x 256k = 5e8 pairs), checked through properties
+    that do not depend on size: planted identical pairs score 0, duplicated subjects agree
+    wherever they sit (other group, other lane, other block), shuffling the subjects permutes the
+    columns, the distance is symmetric in its arguments, and a random sample equals the oracle."""
+    import torch
+    rng = np.random.default_rng(7)
+    nq, ns = 2000, 256 * 1024
+    q = oracle.gen_reads(81, nq, 150)
+    s = oracle.gen_reads(82, ns, 150)
+    planted = rng.choice(ns, size=nq, replace=False)
+    s[planted] = q                                    # subject planted[i] == query i
+    dup_src = rng.choice(ns, size=4096, replace=False)
+    dup_dst = (dup_src + ns // 2 + 37) % ns
+    keep = ~np.isin(dup_dst, planted) & ~np.isin(dup_dst, dup_src)
+    dup_src, dup_dst = dup_src[keep], dup_dst[keep]
+    s[dup_dst] = s[dup_src]
+    a = B.DeviceAligner(B.ALGO_MYERS)
+    a.set_queries(q)
+    a.set_subjects(s)
+    scores = a.score()
+    idx = torch.arange(nq, device="cuda:0")
+    assert bool((scores[idx, torch.from_numpy(planted).cuda()] == 0).all())
+    assert bool((scores[:, torch.from_numpy(dup_src).cuda()] == scores[:, torch.from_numpy(dup_dst).cuda()]).all())
+    assert int(scores.max()) <= 0 and int(scores.min()) >= -150
+    perm = rng.permutation(ns)
+    b = B.DeviceAligner(B.ALGO_MYERS)
+    b.set_queries(q)
+    b.set_subjects(s[perm])
+    assert bool((b.score() == scores[:, torch.from_numpy(perm).cuda()]).all())
+    # symmetry: d(q_i, s_j) == d(s_j, q_i) on a 64 x 64 corner with roles swapped
+    c = B.DeviceAligner(B.ALGO_MYERS)
+    c.set_queries(s[:64])
+    c.set_subjects(q[:64])
+    assert bool((c.score() == scores[:64, :64].T).all())
+    qi = rng.integers(0, nq, 3000)
+    sj = rng.integers(0, ns, 3000)
+    got = scores[torch.from_numpy(qi).cuda(), torch.from_numpy(sj).cuda()].cpu().numpy()
+    want = np.array([oracle.myers64(q[i:i + 1], s[j:j + 1])[0, 0] for i, j in zip(qi[:400], sj[:400])])
+    assert np.array_equal(got[:400], want)
+
+
 def test_bad_arguments_fail_loudly():
     L = B.lib()
     assert L.bgsa_hip_cal_align_score_dev(B.ALGO_MYERS, None, None, None, 150, 150, 64, 0, 1, 5, 0, None, 0, None) == -1
