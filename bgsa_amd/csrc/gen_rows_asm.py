@@ -14,7 +14,10 @@ v_alignbit_b32, a slow-issue-class instruction on gfx950 (rows_ir.py, scripts/ub
 
 Control flow is threaded code: the query is a packed stream of one-byte codes (0..4 = A C G T N
 row bodies, 5 = END, 6 = REFILL), 7 characters + 1 REFILL per 8-byte window, fetched with
-s_load_dwordx2 one window ahead (bgsa_common.h "Packed query stream").  Each body ends with the
+s_load_dwordx2 one window ahead (bgsa_common.h "Packed query stream").  (`glc` on these loads was
+measured: -3 % Myers, -37 % banded — the short banded rows do not cover an L2 round trip — and an
+extra s_dcache_inv per wave cost 3 %; the dispatch's own acquire fence is what keeps the scalar
+cache coherent with the packer kernel's stores, as for any kernel argument.)  Each body ends with the
 dispatch of the next code (s_and / s_lshr_b64 / s_mul / s_add / s_addc / s_setpc): a row costs one
 taken branch and no loop counter.  All five bodies have the same byte length (same opcodes and
 operand classes), so the jump target is base + code * stride, both computed by the assembler from

@@ -184,6 +184,32 @@ def test_large_batch_properties(oracle):
     assert np.array_equal(got[:400], want)
 
 
+def test_fuzz_all_algorithms(oracle):
+    """Random lengths / counts / thresholds / alphabets through every kernel family."""
+    rng = np.random.default_rng(2026)
+    alphabet = np.frombuffer(b"ACGTACGTACGTNacgtX-", dtype=np.uint8)
+    for trial in range(60):
+        algo = (B.ALGO_MYERS, B.ALGO_BITPAL, B.ALGO_BANDED)[trial % 3]
+        nq, ns = int(rng.integers(1, 6)), int(rng.integers(1, 150))
+        if algo == B.ALGO_BANDED:
+            k = int(rng.integers(1, 32))
+            qlen = slen = int(rng.integers(2 * k + 2, 400))
+        else:
+            k = 0
+            qlen, slen = int(rng.integers(1, 330)), int(rng.integers(1, 1200 if algo == B.ALGO_MYERS else 330))
+        q = alphabet[rng.integers(0, len(alphabet), (nq, qlen))]
+        s = alphabet[rng.integers(0, len(alphabet), (ns, slen))]
+        m = min(qlen, slen)
+        near = min(ns, 8)
+        s[:near, :m] = q[rng.integers(0, nq, near)][:, :m]
+        flip = rng.random((near, m)) < 0.04
+        s[:near, :m][flip] = alphabet[rng.integers(0, 4, int(flip.sum()))]
+        got = B.align_all_pairs(q, s, algo=algo, k=k)
+        want = {B.ALGO_MYERS: lambda: oracle.myers64(q, s), B.ALGO_BITPAL: lambda: oracle.bitpal(q, s),
+                B.ALGO_BANDED: lambda: oracle.banded64(q, s, k)}[algo]()
+        assert np.array_equal(got, want), (trial, algo, nq, ns, qlen, slen, k)
+
+
 def test_bad_arguments_fail_loudly():
     L = B.lib()
     assert L.bgsa_hip_cal_align_score_dev(B.ALGO_MYERS, None, None, None, 150, 150, 64, 0, 1, 5, 0, None, 0, None) == -1
