@@ -65,6 +65,7 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_cal_align_score_dev.argtypes = [i32, vp, vp, vp, i32, i32, i64, i32, i32, i32, i32, vp, sz, vp]
     L.bgsa_hip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.bgsa_hip_workspace_bytes.restype = sz
+    L.bgsa_hip_query_stream.argtypes = [i32, vp, i32, i32, vp, i32]
     L.bgsa_hip_kernel_name.argtypes = [i32, i32]
     L.bgsa_hip_kernel_name.restype = ctypes.c_char_p
     L.bgsa_hip_malloc.argtypes = [ctypes.POINTER(vp), sz]

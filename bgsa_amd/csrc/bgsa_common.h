@@ -39,6 +39,26 @@ const char *myers_kernel_name(int word_num);
 constexpr int kCodeEnd = 5, kCodeRefill = 6;
 inline int stream_windows(int ref_len) { return ref_len / 7 + 1; }
 inline size_t stream_stride(int ref_len) { return static_cast<size_t>(stream_windows(ref_len) + 1) * 8; }
+// Window `i` of the plain stream of one query (row = its mapped characters); i == n_windows is the
+// spare all-END window.  Shared by the packer kernel and the host-side introspection entry point.
+__host__ __device__ inline unsigned long long plain_stream_window(const char *row, int ref_len, int i)
+{
+    const int n_windows = ref_len / 7 + 1;
+    unsigned long long win = 0;
+    for (int j = 0; j < 8; j++) {
+        unsigned code = kCodeEnd;
+        if (i < n_windows) {
+            const int pos = 7 * i + j;
+            if (j == 7) code = (i < n_windows - 1) ? kCodeRefill : kCodeEnd;
+            else if (pos < ref_len) {
+                code = static_cast<unsigned char>(row[pos]);
+                if (code > 4) code = 0;  // the reference would index Peq out of range; treat as 'A'
+            }
+        }
+        win |= static_cast<unsigned long long>(code) << (8 * j);
+    }
+    return win;
+}
 int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
                         void *d_streams, hipStream_t stream);
 

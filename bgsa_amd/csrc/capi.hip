@@ -269,6 +269,23 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
     }
 }
 
+int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, unsigned char *dst, int cap)
+{
+    if (!mapped_row || ref_len <= 0) return BGSA_HIP_EINVAL;
+    if (algo == BGSA_ALGO_BANDED) {
+        const int n = banded_stream_layout(ref_len, k, nullptr, nullptr);
+        if (dst && cap >= n) banded_stream_layout(ref_len, k, mapped_row, dst);
+        return n;
+    }
+    const int n = static_cast<int>(stream_stride(ref_len));
+    if (dst && cap >= n)
+        for (int i = 0; i <= stream_windows(ref_len); i++) {
+            const unsigned long long w = plain_stream_window(mapped_row, ref_len, i);
+            memcpy(dst + 8 * i, &w, 8);
+        }
+    return n;
+}
+
 const char *bgsa_hip_kernel_name(int algo, int word_num)
 {
     switch (algo) {

@@ -112,19 +112,7 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const char *__restric
     if (tid >= static_cast<long long>(n_queries) * per) return;
     const int q = static_cast<int>(tid / per), i = static_cast<int>(tid % per);
     const char *row = content + static_cast<size_t>(ref_start + q) * (ref_len + 1);
-    unsigned long long win = 0;
-    for (int j = 0; j < 8; j++) {
-        unsigned code = kCodeEnd;
-        if (i < n_windows) {
-            const int pos = 7 * i + j;
-            if (j == 7) code = (i < n_windows - 1) ? kCodeRefill : kCodeEnd;
-            else if (pos < ref_len) {
-                code = static_cast<uint8_t>(row[pos]);
-                if (code > 4) code = 0;  // the reference would index Peq out of range; treat as 'A'
-            }
-        }
-        win |= static_cast<unsigned long long>(code) << (8 * j);
-    }
+    const unsigned long long win = plain_stream_window(row, ref_len, i);
     streams[tid] = win;
 }
 

@@ -105,3 +105,52 @@ def test_host_handle_reads_layout_banded(L, oracle):
                 bit = (int(peq[0, cc, i // W, s]) >> (i % W)) & 1
                 assert bit == (cc == CODE[padded[s, p]])
         assert int(np.bitwise_count(peq[0, :, :, s]).sum()) == 150
+
+
+def _decode_stream(raw):
+    """Walk a packed stream the way the row loop does: returns the token list."""
+    tokens, pos, win = [], 0, 0
+    while True:
+        base = 8 * win
+        code = raw[base + pos]
+        pos += 1
+        if code <= 4:
+            tokens.append(("row", int(code)))
+        elif code == 5:
+            return tokens
+        elif code == 6:
+            win, pos = win + 1, 0
+        else:
+            tokens.append(("event", int(raw[base + pos])))
+            pos += 1
+        assert pos <= 8
+
+
+@pytest.mark.parametrize("qlen", [1, 6, 7, 8, 14, 150, 151, 1000])
+def test_plain_query_stream(L, qlen):
+    rng = np.random.default_rng(qlen)
+    row = rng.integers(0, 5, qlen).astype(np.uint8)
+    n = L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, 0, None, 0)
+    assert n == (qlen // 7 + 2) * 8
+    buf = np.full(n, 0xEE, dtype=np.uint8)
+    assert L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, 0, buf.ctypes.data, n) == n
+    assert [t for t in _decode_stream(buf)] == [("row", int(c)) for c in row]
+    assert (buf[-8:] == 5).all()                       # the spare window the loop may prefetch
+    assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_MYERS, qlen, 150, 3) == 3 * n
+
+
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 1), (150, 15), (64, 8), (65, 3), (33, 2), (1000, 8)])
+def test_banded_query_stream_matches_the_token_model(L, length, k):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(B.__file__).resolve().parent / "csrc"))
+    import rows_ir as R
+    rng = np.random.default_rng(length + k)
+    row = rng.integers(0, 5, length).astype(np.uint8)
+    n = L.bgsa_hip_query_stream(B.ALGO_BANDED, row.ctypes.data, length, k, None, 0)
+    buf = np.full(n, 0xEE, dtype=np.uint8)
+    assert L.bgsa_hip_query_stream(B.ALGO_BANDED, row.ctypes.data, length, k, buf.ctypes.data, n) == n
+    want = [("row", int(row[v])) if kind == "row" else ("event", v) for kind, v in R.banded_tokens(length, k)]
+    assert _decode_stream(buf) == want
+    assert n % 8 == 0 and (buf[-8:] == 5).all()
+    assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_BANDED, length, length, 2) >= 2 * n

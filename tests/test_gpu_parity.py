@@ -184,6 +184,27 @@ def test_large_batch_properties(oracle):
     assert np.array_equal(got[:400], want)
 
 
+@pytest.mark.parametrize("length", [31, 32, 33, 64, 150, 160, 256, 257, 512, 1000, 1024])
+def test_long_carry_chains(oracle, length):
+    """Inputs that drive the inter-word carry chains end to end: identical homopolymers (the
+    addition carries across every word), a single mismatch at each end, period-2 repeats against
+    their shift, all-N reads."""
+    def rows(*seqs):
+        return np.stack([np.frombuffer(x, dtype=np.uint8) for x in seqs])
+    a, c = b"A" * length, b"C" * length
+    ac = (b"AC" * length)[:length]
+    ca = (b"CA" * length)[:length]
+    q = rows(a, c, ac, b"T" + a[1:], a[:-1] + b"G", b"N" * length)
+    s = np.concatenate([q, rows(ca, c[:-1] + b"A", b"G" + c[1:])] * 8)
+    for algo, fn in ((B.ALGO_MYERS, oracle.myers64), (B.ALGO_BITPAL, oracle.bitpal)):
+        if algo == B.ALGO_BITPAL and length > 512:
+            continue  # state-in-memory kernel: covered elsewhere, slow on purpose
+        assert np.array_equal(B.align_all_pairs(q, s, algo=algo), fn(q, s))
+    if length > 40:
+        for k in (8, 20):
+            assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BANDED, k=k), oracle.banded64(q, s, k))
+
+
 def test_fuzz_all_algorithms(oracle):
     """Random lengths / counts / thresholds / alphabets through every kernel family."""
     rng = np.random.default_rng(2026)
