@@ -210,6 +210,29 @@ def main() -> int:
     # size-independent sanity on the full-size output: diagonal-free checksum properties
     checksum = int(out[:, :ns].to(torch.int64).sum().item()) if rank == 0 else 0
 
+    # Outside the timed region, N > 1 only: the score gather of SURVEY §2a C3 — every rank's
+    # [REF_BUCKET_COUNT, subjects] tile to rank 0 over xGMI (RCCL), timed once for the record.
+    gather_info = None
+    if dist is not None and world > 1:
+        try:
+            from bgsa_amd.multi_gpu import Shard, ShardedAligner
+            sa = ShardedAligner(dist=dist, device=dev, score_fn=lambda *_: None, algo=algo, k=k)
+            tile = out[:100, :ns].contiguous()
+            shards = [Shard(r * ns, ns) for r in range(world)]
+            fence()
+            g0 = time.perf_counter()
+            gathered = sa.gather_scores(tile, shards, layout="row_major")
+            fence()
+            g1 = time.perf_counter()
+            if rank == 0:
+                ok = bool((gathered[:, :ns] == tile).all())
+                gather_info = {"what": "100-query score tiles of all ranks to rank 0 (RCCL gather, outside the timed steps)",
+                               "bytes_per_rank": int(tile.numel() * tile.element_size()), "ms": round((g1 - g0) * 1e3, 3),
+                               "rank0_tile_intact": ok}
+            del gathered
+        except Exception as e:  # never let the optional leg break the benchmark line
+            gather_info = {"error": repr(e)}
+
     cells_per_step_rank = float(nq) * ns * length * length
     gcups = cells_per_step_rank * world * args.steps / elapsed / 1e9
     result = None
@@ -263,6 +286,8 @@ def main() -> int:
             },
             "checksum": checksum,
         }
+        if gather_info:
+            result["gather"] = gather_info
         if not args.no_cpu_baseline and world == 1:
             cq, cs = (int(x) for x in args.cpu_sample.split("x"))
             cq, cs = min(cq, nq), min(cs, ns) // 8 * 8

@@ -6,20 +6,26 @@
 // Mapping to the machine
 //   * lane  = one subject; a wavefront = one "group" of HIP_V_NUM = 64 subjects, which is exactly
 //     the reference's SIMD-lane layout [group][char][word][lane] widened from 4/8/16 to 64 lanes.
-//   * The subject's match masks Peq[5][NW] stay in VGPRs for the whole task; a task scores a
-//     tile of queries against the group, so each Peq block is read from HBM once per tile.
+//   * The subject's match masks stay in VGPRs for the whole task; a task scores a tile of
+//     queries against the group, so each Peq block is read from HBM once per tile.
 //   * The query character is wave-uniform: it is fetched through the scalar cache and selects
-//     one of five copies of the row body by a scalar branch, so `Eq = Peq[c][w]` costs no VALU
+//     one of five copies of the row body by a scalar jump, so `Eq = Peq[c][w]` costs no VALU
 //     work (the reference pays a pointer add + a vector load per word, align_core.c:67,74).
 //   * Words are full 32-bit (the reference keeps bit W-1 free as a software carry,
-//     align_core.c:79-83,91-96): the add carry rides the hardware carry chain
-//     (v_add_co/v_addc_co), and the HP/HN shift carry is one v_alignbit_b32 funnel shift.
+//     align_core.c:79-83,91-96): the addition and both 1-bit shifts are add-with-carry chains
+//     through VCC.
 //   * The score is not tracked per row (align_core.c:121-124); after the last row
 //     D[m][n] = m + popcount(VP & mask) - popcount(VN & mask), two v_bcnt per word.
-//   Per (query row, word): 10 VALU ops (v_and, v_addc_co, 5 x v_bitop3/v_or/v_and, 2 x
-//   v_alignbit) against the reference's 24.
 //
-// Integer/bitwise only; no LDS, no MFMA.  The kernel is VALU-issue bound.
+// Three kernels, chosen by launch_myers():
+//   myers_global_asm_kernel<NW,1>   1..256 bp    generated asm row loop, 10 VALU per (row, word)
+//   myers_global_planes_kernel<NW>  257..1024 bp generated asm row loop on 3-bit character-code
+//                                                planes, 11 VALU per (row, word)
+//   myers_global_kernel<NW,1>       compiler-scheduled C++ of the same recurrence: the A/B
+//                                   reference for the asm (BGSA_MYERS_IMPL=c), 124 vs 216 TCUPS
+//   (> 1024 bp: long_kernels.hip, state in memory.)
+//
+// Integer/bitwise only; no LDS, no MFMA.  The kernels are VALU-issue bound.
 #include <stdlib.h>
 
 #include "bgsa_common.h"
