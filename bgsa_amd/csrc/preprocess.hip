@@ -55,6 +55,51 @@ __global__ __launch_bounds__(256) void preprocess_global_kernel(const char *__re
     }
 }
 
+// Short reads (64 rows fit in 16 KB of LDS): the 64 rows of a group are one contiguous byte range
+// of the input, so the wave stages them with fully coalesced 16-byte loads and each lane then
+// walks its own row in LDS — the global reads are at streaming efficiency instead of 64 strided
+// byte streams.  One wave per group, four groups per workgroup.
+__global__ __launch_bounds__(256) void preprocess_global_lds_kernel(const char *__restrict__ rows,
+                                                                    uint32_t *__restrict__ peq, int len,
+                                                                    long long n_groups, int word_num,
+                                                                    long long total_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long group = static_cast<long long>(blockIdx.x) * kWavesPerBlock + wave;
+    const int row_bytes = len + 1;
+    const int group_bytes = 64 * row_bytes;
+    const int slot_bytes = (group_bytes + 15 + 16) & ~15;  // +16: the group may start mid-16-byte line
+    unsigned char *mine = stage + wave * slot_bytes;
+    if (group < n_groups) {
+        const long long first = group * group_bytes;                 // byte offset of the group's rows
+        const long long aligned = first & ~15LL;
+        const int skew = static_cast<int>(first - aligned);
+        const uint4 *src = reinterpret_cast<const uint4 *>(rows + aligned);
+        const int n16 = (skew + group_bytes + 15) / 16;
+        for (int i = lane; i < n16; i += 64) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (aligned + 16LL * i + 16 <= ((total_bytes + 15) & ~15LL)) v = src[i];  // stays inside the allocation's last line
+            reinterpret_cast<uint4 *>(mine)[i] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned char *row = mine + skew + lane * row_bytes;
+        uint32_t *dst = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+        for (int w = 0; w < word_num; w++) {
+            uint32_t m[kChars] = {0, 0, 0, 0, 0};
+            const int base = w * 32;
+            const int n = min(32, len - base);
+            for (int b = 0; b < n; b++) {
+                const uint32_t c = map_char(row[base + b]);
+#pragma unroll
+                for (uint32_t cc = 0; cc < kChars; cc++) m[cc] |= static_cast<uint32_t>(c == cc) << b;
+            }
+#pragma unroll
+            for (int cc = 0; cc < kChars; cc++) dst[(cc * word_num + w) * kLanes] = m[cc];
+        }
+    }
+}
+
 // ---- banded layout ------------------------------------------------------------------------------
 // "Mext": per character class, the subject's match bit-string offset by k+1 zero bits — bit i is
 // set iff i >= k+1 and subject[i-(k+1)] maps to the class.  Words 0 of the reference's layout
@@ -158,7 +203,6 @@ int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len
 {
     if (read_count == 0) return BGSA_HIP_OK;
     const unsigned blocks = static_cast<unsigned>((read_count + 255) / 256);
-    (void)avail_bytes;
     if (algo == BGSA_ALGO_BANDED && k <= 15) {
         hipLaunchKernelGGL(preprocess_banded_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, d_rows,
                            d_peq, len, static_cast<long long>(read_count), word_num, k);
@@ -166,6 +210,13 @@ int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len
         hipLaunchKernelGGL(preprocess_banded_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, d_rows,
                            reinterpret_cast<uint64_t *>(d_peq), len, static_cast<long long>(read_count),
                            word_num, k);
+    } else if (64 * (len + 1) + 32 <= 16 * 1024 && (reinterpret_cast<uintptr_t>(d_rows) & 15) == 0 &&
+               avail_bytes >= read_count * (len + 1)) {
+        const long long n_groups = read_count / kLanes;
+        const int slot = (64 * (len + 1) + 15 + 16) & ~15;
+        hipLaunchKernelGGL(preprocess_global_lds_kernel, dim3(static_cast<unsigned>((n_groups + 3) / 4)), dim3(256),
+                           static_cast<size_t>(slot) * kWavesPerBlock, stream, d_rows, d_peq, len, n_groups, word_num,
+                           static_cast<long long>(avail_bytes));
     } else {
         hipLaunchKernelGGL(preprocess_global_kernel, dim3(blocks), dim3(256), 0, stream, d_rows,
                            d_peq, len, static_cast<long long>(read_count), word_num, 32);
