@@ -135,6 +135,7 @@ def main() -> int:
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--nq", type=int, default=None, help="override query count (not the BASELINE config)")
     ap.add_argument("--ns", type=int, default=None, help="override subjects per GPU (not the BASELINE config)")
+    ap.add_argument("--length", type=int, default=None, help="override read length (not the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="2000x100000", help="queries x subjects timed on the CPU")
     args = ap.parse_args()
@@ -156,9 +157,10 @@ def main() -> int:
         dist.init_process_group("nccl", device_id=dev)
 
     algo, cfg_name, nq, ns, length, k = CONFIGS[args.config]
-    overridden = args.nq is not None or args.ns is not None
+    overridden = args.nq is not None or args.ns is not None or args.length is not None
     nq = args.nq or nq
     ns = args.ns or ns
+    length = args.length or length
     ns_pad = (ns + 63) // 64 * 64
 
     # ---- synthetic workload: uniform i.i.d. A/C/G/T, generated on the GPU -------------------------

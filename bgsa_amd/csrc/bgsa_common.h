@@ -112,6 +112,35 @@ __host__ __device__ inline int banded_stream_layout(int len, int k, const char *
     }
     return pos;
 }
+// Stream of the column-block Myers kernel: row codes with a CARRY token (code 7, no argument)
+// in front of every 32nd row (rows_ir.py: myers_blocked_simulate).  Same contract as
+// banded_stream_layout.
+__host__ __device__ inline int blocked_stream_layout(int len, const char *row, unsigned char *dst)
+{
+    int pos = 0, slot = 0;
+    auto put = [&](unsigned char b) {
+        if (dst) dst[pos] = b;
+        pos++;
+        if (++slot == 7) {
+            if (dst) dst[pos] = kCodeRefill;
+            pos++;
+            slot = 0;
+        }
+    };
+    for (int r = 0; r < len; r++) {
+        if (r > 0 && (r & 31) == 0) put(7);
+        unsigned char code = 0;
+        if (row) { code = static_cast<unsigned char>(row[r]); if (code > 4) code = 0; }
+        put(code);
+    }
+    put(kCodeEnd);
+    while (pos & 7) { if (dst) dst[pos] = kCodeEnd; pos++; }
+    for (int i = 0; i < 8; i++) { if (dst) dst[pos] = kCodeEnd; pos++; }
+    return pos;
+}
+int launch_pack_blocked(const char *d_content, int len, int ref_start, int ref_end, void *d_streams,
+                        hipStream_t stream);
+
 int launch_pack_banded(const char *d_content, int len, int k, int ref_start, int ref_end, void *d_streams,
                        hipStream_t stream);
 
@@ -128,7 +157,13 @@ const char *bitpal_kernel_name(int word_num);
 // long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.
 inline bool needs_long_kernel(int algo, int word_num)
 {
-    return (algo == BGSA_ALGO_MYERS && word_num > kMaxWords) || (algo == BGSA_ALGO_BITPAL && word_num > 8);
+    return algo == BGSA_ALGO_BITPAL && word_num > 8;  // Myers > 1024 bp: column blocks (myers_global.hip)
+}
+// Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.
+constexpr int kBlockedBlocks = 512;  // persistent workgroups of myers_blocked_kernel
+inline size_t blocked_carry_bytes(int ref_len)
+{
+    return static_cast<size_t>((ref_len + 31) / 32) * 3 * kLanes * sizeof(uint32_t) * kWavesPerBlock * kBlockedBlocks;
 }
 size_t long_state_bytes(int algo, int word_num);
 int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,

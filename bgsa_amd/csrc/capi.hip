@@ -217,6 +217,12 @@ size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queri
 {
     if (ref_len <= 0 || n_queries <= 0) return 0;
     if (read_len > 0 && needs_long_kernel(algo, (read_len + 31) / 32)) return long_state_bytes(algo, (read_len + 31) / 32);
+    if (algo == BGSA_ALGO_MYERS && (read_len + 31) / 32 > kMaxWords) {  // column blocks: streams + carry buffers
+        const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
+                               blocked_carry_bytes(ref_len);
+        const size_t in_memory = long_state_bytes(algo, (read_len + 31) / 32);  // BGSA_MYERS_IMPL=c
+        return blocked > in_memory ? blocked : in_memory;
+    }
     if (algo == BGSA_ALGO_BANDED)  // event tokens make the stream longer; k = 1 is the longest
         return static_cast<size_t>(banded_stream_layout(ref_len, 1, nullptr, nullptr) + 16) * n_queries;
     return stream_stride(ref_len) * static_cast<size_t>(n_queries);
@@ -275,6 +281,11 @@ int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, 
     if (algo == BGSA_ALGO_BANDED) {
         const int n = banded_stream_layout(ref_len, k, nullptr, nullptr);
         if (dst && cap >= n) banded_stream_layout(ref_len, k, mapped_row, dst);
+        return n;
+    }
+    if (algo == BGSA_ALGO_MYERS && k < 0) {  // k < 0: the column-block stream (subjects > 1024 bp)
+        const int n = blocked_stream_layout(ref_len, nullptr, nullptr);
+        if (dst && cap >= n) blocked_stream_layout(ref_len, mapped_row, dst);
         return n;
     }
     const int n = static_cast<int>(stream_stride(ref_len));

@@ -33,6 +33,7 @@ import rows_ir as R  # noqa: E402
 
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8]
 MYERS_PLANES_NW = [12, 16, 20, 24, 28, 32]
+MYERS_BLOCK_NW = [20, 24, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
 BITPAL_NW = [1, 2, 3, 4, 5, 6, 7, 8]
 
 # Scalar scratch registers, hard-coded and declared as clobbers (inline asm cannot name the
@@ -283,6 +284,94 @@ __device__ __forceinline__ unsigned long long banded_rows_asm(uint32_t (&state)[
 """
 
 
+def gen_blocked_function(nw: int) -> str:
+    """Row loop of myers_blocked_kernel<NW>: one column block of a long subject.  Stream code 7
+    (no argument) every 32 rows = CARRY: store the three carry-out words of the finished 32 rows
+    to the wave's carry buffer, fetch the three carry-in words of the next 32 rows."""
+    body = R.myers_block_body(nw)
+    slot_of, n_slots = body.allocate_temps()
+    S_CB = "s[80:81]"
+    clobbers = CLOBBERS[:-3] + ["s80", "s81", "vcc", "scc", "memory"]
+    cin = [2 * nw + i for i in range(3)]
+    cout = [2 * nw + 3 + i for i in range(3)]
+
+    def reg_for(c: int):
+        def reg(name: str) -> str:
+            if name.startswith("S"):
+                return f"%[s{name[1:]}]"
+            if name.startswith("B"):
+                return f"%[b{name[1:]}]"
+            return f"%[t{slot_of[name]}]"
+        return reg
+
+    asm = [
+        f"s_mov_b64 {S_PTR}, %[qp]",
+        f"s_mov_b32 {S_LEFT}, %[nwin]",
+        f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+        f"s_mov_b64 {S_CB}, %[cbase]",
+        f"s_getpc_b64 {S_PC}",
+        "L_anchor_%=:",
+        f"s_add_u32 {S_BASE_LO}, {S_PC_LO}, (L_body0_%= - L_anchor_%=)",
+        f"s_addc_u32 {S_BASE_HI}, {S_PC_HI}, 0",
+        "s_waitcnt lgkmcnt(0)",
+    ]
+    asm += dispatch()
+    for c in range(5):
+        asm.append(f"L_body{c}_%=:")
+        asm += body.emit_asm(reg_for(c), c)
+        asm += dispatch()
+    asm.append("L_body5_%=:")
+    asm.append("s_branch L_done_%=")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - 4) / 4, 4, 0xbf800000")
+    asm.append("L_body6_%=:")
+    asm += [
+        f"s_sub_u32 {S_LEFT}, {S_LEFT}, 1",
+        "s_cbranch_scc1 L_done_%=",
+        "s_waitcnt lgkmcnt(0)",
+        f"s_mov_b64 {S_WIN}, {S_NXT}",
+        f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 8",
+        f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+    ]
+    asm += dispatch()
+    asm.append("L_refill_end_%=:")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
+    asm.append("L_body7_%=:")  # CARRY: chunk j out, chunk j+1 in ([chunk][3][64 lanes] dwords)
+    asm += [f"global_store_dword %[voff], %[s{cout[i]}], {S_CB} offset:{256 * i}" for i in range(3)]
+    asm.append("v_add_u32 %[voff], 0x300, %[voff]")
+    asm += [f"global_load_dword %[s{cin[i]}], %[voff], {S_CB} offset:{256 * i} sc1" for i in range(3)]
+    asm.append("s_waitcnt vmcnt(0)")
+    asm += dispatch()
+    asm.append("L_done_%=:")
+    asm.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+
+    n_state = 2 * nw + 6
+    text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += ['[voff] "+v"(voff)']
+    outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
+    ins = [f'[b{j}] "v"(B[{j}])' for j in range(3 * nw)]
+    ins += ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[cbase] "s"(carry_base)']
+    clob = ", ".join(f'"{x}"' for x in clobbers)
+    nops = sum(line.startswith("s_nop") for line in body.emit_asm(lambda x: x, 0))
+    return f"""
+// {body.valu_count()} VALU per row, {n_slots} temporaries, {nops} hazard nops
+template <>
+__device__ __forceinline__ void myers_block_rows_asm<{nw}>(uint32_t (&state)[{n_state}], const uint32_t (&B)[{3 * nw}],
+                                                       uint32_t &voff, const unsigned long long carry_base,
+                                                       const unsigned long long stream, const int n_windows)
+{{
+    uint32_t tmp[{max(n_slots, 1)}];
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+}}
+"""
+
+
 def main() -> int:
     here = Path(__file__).resolve().parent
     head = "// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n"
@@ -305,6 +394,15 @@ def main() -> int:
                  "                                                      const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PLANES_NW:
         parts.append(gen_function("myers_planes_rows_asm", f"{nw}", R.myers_planes_body(nw), 2 * nw, 0, n_planes=3 * nw))
+    parts.append("\n// One column block of a subject longer than 1024 bp (rows_ir.py:myers_block_body).  state =\n"
+                 "// {VP, VN} x NW, carry-in words (add, HP, HN), carry-out words; voff = this lane's byte offset\n"
+                 "// of the current 32-row chunk in the wave's carry buffer ([chunk][3][64] dwords at carry_base).\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ void myers_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&B)[3 * NW],\n"
+                 "                                                     uint32_t &voff, const unsigned long long carry_base,\n"
+                 "                                                     const unsigned long long stream, const int n_windows);\n")
+    for nw in MYERS_BLOCK_NW:
+        parts.append(gen_blocked_function(nw))
     (here / "myers_rows_gen.inc").write_text("".join(parts))
     # ---- BitPAl -------------------------------------------------------------------------------
     parts = [head,

@@ -23,7 +23,8 @@
 //                                                planes, 11 VALU per (row, word)
 //   myers_global_kernel<NW,1>       compiler-scheduled C++ of the same recurrence: the A/B
 //                                   reference for the asm (BGSA_MYERS_IMPL=c), 124 vs 216 TCUPS
-//   (> 1024 bp: long_kernels.hip, state in memory.)
+//   myers_blocked_kernel<NW>        > 1024 bp    column blocks of the planes body, carries between
+//                                                blocks through per-wave carry words
 //
 // Integer/bitwise only; no LDS, no MFMA.  The kernels are VALU-issue bound.
 #include <stdlib.h>
@@ -239,6 +240,87 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
     }
 }
 
+// Subjects longer than 1024 bp: column blocks of NW words.  For each query the wave runs the
+// generated row loop once per block; the three carry chains of row r cross the block boundary
+// through its carry buffer ([32-row chunk][add, HP, HN][lane] words in the workspace, first row in
+// bit 31 — rows_ir.py: myers_block_body).  A fixed number of workgroups loops over the tasks so
+// that the buffer count does not grow with the problem.
+template <int NW>
+__global__ __launch_bounds__(256) void myers_blocked_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
+    uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int wave = threadIdx.x >> 6;
+    const int n_chunks = (ref_len + 31) / 32;
+    uint32_t *carry = carry_all + (static_cast<size_t>(blockIdx.x) * kWavesPerBlock + wave) * n_chunks * 3 * kLanes;
+    const unsigned long long carry_base = uniform_u64(reinterpret_cast<unsigned long long>(carry));
+    const int q_tiles = (n_queries + q_tile - 1) / q_tile;
+    const long long n_tasks = static_cast<long long>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock) * q_tiles;
+    const int tail_rows = ref_len & 31;
+
+    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int group = __builtin_amdgcn_readfirstlane(static_cast<int>(task / q_tiles) * kWavesPerBlock + wave);
+        const int tile = static_cast<int>(task % q_tiles);
+        if (group >= n_groups) continue;  // wave-uniform
+        const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+        const int q0 = tile * q_tile;
+        const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+        for (int q = q0; q < q1; q++) {
+            // carry-in of block 0: addition 0, HP 1 (the row edge D[i][0] - D[i-1][0] = +1), HN 0
+            for (int c = 0; c < n_chunks; c++) {
+                carry[(c * 3 + 0) * kLanes + lane] = 0u;
+                carry[(c * 3 + 1) * kLanes + lane] = ~0u;
+                carry[(c * 3 + 2) * kLanes + lane] = 0u;
+            }
+            const unsigned long long s =
+                reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+            int score = ref_len;
+            for (int blk = 0; blk < n_blocks; blk++) {
+                uint32_t Bp[3 * NW];
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const int gw = blk * NW + w;
+                    uint32_t p[kChars];
+#pragma unroll
+                    for (int c = 0; c < kChars; c++) p[c] = (gw < word_num) ? g[(c * word_num + gw) * kLanes] : 0u;
+                    Bp[3 * w + 0] = p[1] | p[3];
+                    Bp[3 * w + 1] = p[2] | p[3];
+                    Bp[3 * w + 2] = p[4];
+                }
+                uint32_t st[2 * NW + 6];
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    st[2 * w] = ~0u;
+                    st[2 * w + 1] = 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    st[2 * NW + i] = carry[i * kLanes + lane];  // chunk 0
+                    st[2 * NW + 3 + i] = 0u;
+                }
+                uint32_t voff = static_cast<uint32_t>(lane * 4);
+                myers_block_rows_asm<NW>(st, Bp, voff, carry_base, uniform_u64(s),
+                                         __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                // carry-out words of the last (possibly partial) chunk, first row left-aligned
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const uint32_t word = tail_rows ? (st[2 * NW + 3 + i] << (32 - tail_rows)) : st[2 * NW + 3 + i];
+                    carry[((n_chunks - 1) * 3 + i) * kLanes + lane] = word;
+                }
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const int rem = read_len - 32 * (blk * NW + w);
+                    const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                    score += __popc(st[2 * w] & m) - __popc(st[2 * w + 1] & m);
+                }
+            }
+            out[static_cast<size_t>(q) * ld + static_cast<size_t>(group) * kLanes + lane] = static_cast<int16_t>(-score);
+        }
+    }
+}
+
 namespace {
 
 // Register-resident word counts that are instantiated; a subject uses the smallest one that
@@ -319,6 +401,41 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
     return BGSA_HIP_OK;
 }
 
+template <int NW>
+int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
+                   int64_t read_count, int ref_start, int ref_end, int word_num, int n_blocks, void *d_workspace,
+                   hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int stride = blocked_stream_layout(ref_len, nullptr, nullptr);
+    const size_t stream_bytes = (static_cast<size_t>(stride) * nq + 255) & ~static_cast<size_t>(255);
+    if (int rc = launch_pack_blocked(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
+    hipLaunchKernelGGL((myers_blocked_kernel<NW>), dim3(kBlockedBlocks), dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
+                       static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
+                       stride, n_blocks);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+// Block width for a subject of word_num > 32 words: the narrowest instantiated width that covers
+// it with the fewest blocks (35 words -> 2 x 20, not 2 x 28).  28 words is the widest block that
+// keeps two waves per SIMD (32 needs 256 VGPRs: measured 93 vs 168 TCUPS).
+int pick_block_nw(int word_num, int *n_blocks)
+{
+    constexpr int kWidest = 28;
+    const int blocks = (word_num + kWidest - 1) / kWidest;
+    const int need = (word_num + blocks - 1) / blocks;
+    for (int nw : {20, 24, 28})
+        if (nw >= need) {
+            *n_blocks = (word_num + nw - 1) / nw;
+            return nw;
+        }
+    *n_blocks = blocks;
+    return kWidest;
+}
+
 int pick_planes_nw(int word_num)
 {
     for (int nw : {12, 16, 20, 24, 28, 32})
@@ -353,7 +470,11 @@ const char *myers_kernel_name(int word_num)
 {
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
-    if (nw < 0) return "myers_long_kernel";
+    if (word_num > kMaxWords) {
+        int n_blocks = 0;
+        snprintf(name, sizeof name, "myers_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
+        return name;
+    }
     if (myers_impl() == 0 && word_num > 8 && pick_planes_nw(word_num) > 0)
         snprintf(name, sizeof name, "myers_global_planes_kernel<%d>", pick_planes_nw(word_num));
     else
@@ -366,9 +487,21 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
                  void *d_workspace, hipStream_t stream)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
-    if (needs_long_kernel(BGSA_ALGO_MYERS, word_num))
+    if (word_num > kMaxWords && myers_impl() == 1)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_MYERS, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);
+    if (word_num > kMaxWords) {
+        int n_blocks = 0;
+        switch (pick_block_nw(word_num, &n_blocks)) {
+#define BGSA_BLOCK_CASE(N)                                                                       \
+    case N:                                                                                      \
+        return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
+                                 ref_end, word_num, n_blocks, d_workspace, stream);
+            BGSA_BLOCK_CASE(20) BGSA_BLOCK_CASE(24) BGSA_BLOCK_CASE(28)
+#undef BGSA_BLOCK_CASE
+        default: break;
+        }
+    }
     if (myers_impl() == 0) {
         switch (pick_nw(word_num)) {
 #define BGSA_ASM_CASE(N)                                                                        \

@@ -198,6 +198,28 @@ int launch_pack_banded(const char *d_content, int len, int k, int ref_start, int
     return BGSA_HIP_OK;
 }
 
+__global__ __launch_bounds__(64) void pack_blocked_kernel(const char *__restrict__ content,
+                                                          unsigned char *__restrict__ streams, int len,
+                                                          int ref_start, int n_queries, int stride)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    blocked_stream_layout(len, content + static_cast<size_t>(ref_start + q) * (len + 1),
+                          streams + static_cast<size_t>(q) * stride);
+}
+
+int launch_pack_blocked(const char *d_content, int len, int ref_start, int ref_end, void *d_streams,
+                        hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    if (nq <= 0) return BGSA_HIP_OK;
+    const int stride = blocked_stream_layout(len, nullptr, nullptr);
+    hipLaunchKernelGGL(pack_blocked_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, d_content,
+                       static_cast<unsigned char *>(d_streams), len, ref_start, nq, stride);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
 int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
                       int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream)
 {

@@ -281,6 +281,84 @@ def myers_planes_body(nw: int) -> Body:
     return b
 
 
+def myers_block_body(nw: int) -> Body:
+    """myers_planes_body for one column block of a subject longer than 1024 bp.  The three carry
+    chains enter and leave the block through registers that hold 32 rows' worth of carry bits,
+    first row in bit 31:  x + x  shifts the next row's carry-in into VCC,  x + x + vcc  appends
+    the row's carry-out — six extra fast-class instructions per row, no bit extraction.
+    State: S[2w] = VP, S[2w+1] = VN, then CIN_S, CIN_P, CIN_N, COUT_S, COUT_P, COUT_N."""
+    b = Body()
+    P = lambda w: f"S{w * 2}"
+    M = lambda w: f"S{w * 2 + 1}"
+    D = lambda w: f"d{w}"
+    HP = lambda w: f"hp{w}"
+    CIN = [f"S{2 * nw + i}" for i in range(3)]
+    COUT = [f"S{2 * nw + 3 + i}" for i in range(3)]
+    b.ADD_CO(CIN[0], CIN[0], CIN[0])
+    for w in range(nw):
+        b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}")
+        b.AND(D(w), P(w), "e")
+        b.ADDC(D(w), D(w), P(w))
+        b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
+        b.OR(D(w), D(w), "e")
+    b.ADDC(COUT[0], COUT[0], COUT[0])
+    b.ADD_CO(CIN[1], CIN[1], CIN[1])
+    for w in range(nw):
+        b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
+        b.AND(P(w), D(w), P(w))            # HN parks in the VP register
+        b.ADDC(HP(w), HP(w), HP(w))
+        b.AND(M(w), D(w), HP(w))
+    b.ADDC(COUT[1], COUT[1], COUT[1])
+    b.ADD_CO(CIN[2], CIN[2], CIN[2])
+    for w in range(nw):
+        b.ADDC(P(w), P(w), P(w))
+        b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
+    b.ADDC(COUT[2], COUT[2], COUT[2])
+    return b
+
+
+def myers_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int) -> np.ndarray:
+    """A subject processed as column blocks of nw_block words with the block body, carries
+    exchanged through per-32-row words exactly as myers_blocked_kernel does.  Returns int16."""
+    n, slen = subjects.shape
+    qlen = len(query)
+    nw_total = (slen + 31) // 32
+    n_blocks = (nw_total + nw_block - 1) // nw_block
+    peq = build_peq32(subjects, n_blocks * nw_block)      # zero masks beyond the subject
+    planes_all = code_planes(peq)
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+    n_chunks = (qlen + 31) // 32
+    FULL = np.uint32(0xFFFFFFFF)
+    # carry words per 32-row chunk: addition carry-in 0, HP carry-in 1 (row edge), HN carry-in 0
+    carry = [[np.zeros(n, np.uint32), np.full(n, FULL, np.uint32), np.zeros(n, np.uint32)] for _ in range(n_chunks)]
+    body = myers_block_body(nw_block)
+    score = np.full(n, qlen, dtype=np.int64)
+    for blk in range(n_blocks):
+        st = []
+        for _ in range(nw_block):
+            st += [np.full(n, FULL, np.uint32), np.zeros(n, np.uint32)]
+        st += [c.copy() for c in carry[0]] + [np.zeros(n, np.uint32) for _ in range(3)]
+        planes = planes_all[blk * nw_block * 3:(blk + 1) * nw_block * 3]
+        for r, ch in enumerate(query):
+            if r > 0 and r % 32 == 0:           # the stream's CARRY event
+                j = r // 32
+                carry[j - 1] = [st[2 * nw_block + 3 + i].copy() for i in range(3)]
+                for i in range(3):
+                    st[2 * nw_block + i] = carry[j][i].copy()
+            body.simulate(st, [], cls=code.get(int(ch), 0), planes=planes)
+        tail = qlen % 32
+        last = [st[2 * nw_block + 3 + i] for i in range(3)]
+        if tail:
+            last = [x << np.uint32(32 - tail) for x in last]   # left-align a partial chunk
+        carry[n_chunks - 1] = [x.copy() for x in last]
+        for w in range(nw_block):
+            rem = slen - 32 * (blk * nw_block + w)
+            mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
+            score += np.bitwise_count(st[2 * w] & mask).astype(np.int64)
+            score -= np.bitwise_count(st[2 * w + 1] & mask).astype(np.int64)
+    return (-score).astype(np.int16)
+
+
 def code_planes(peq: np.ndarray) -> list:
     """[5][nw][n] Peq -> class-independent code planes B[w*3+i] (A=0 C=1 G=2 T=3 N=4)."""
     nw = peq.shape[1]

@@ -154,3 +154,28 @@ def test_banded_query_stream_matches_the_token_model(L, length, k):
     assert _decode_stream(buf) == want
     assert n % 8 == 0 and (buf[-8:] == 5).all()
     assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_BANDED, length, length, 2) >= 2 * n
+
+
+@pytest.mark.parametrize("qlen", [1, 31, 32, 33, 64, 100, 1000])
+def test_column_block_query_stream(L, qlen):
+    rng = np.random.default_rng(qlen)
+    row = rng.integers(0, 5, qlen).astype(np.uint8)
+    n = L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, -1, None, 0)
+    buf = np.full(n, 0xEE, dtype=np.uint8)
+    assert L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, -1, buf.ctypes.data, n) == n
+    # walk it: code 7 carries no argument byte in this stream
+    tokens, pos, win = [], 0, 0
+    while True:
+        code = buf[8 * win + pos]
+        pos += 1
+        if code <= 4: tokens.append(int(code))
+        elif code == 5: break
+        elif code == 6: win, pos = win + 1, 0
+        else: tokens.append("carry")
+    want = []
+    for r in range(qlen):
+        if r > 0 and r % 32 == 0:
+            want.append("carry")
+        want.append(int(row[r]))
+    assert tokens == want and (buf[-8:] == 5).all()
+    assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_MYERS, qlen, 2000, 2) >= 2 * n

@@ -54,6 +54,17 @@ def test_myers_planes_body_matches_oracle(oracle, qlen, slen):
         assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
 
 
+@pytest.mark.parametrize("qlen,slen,nwb", [(150, 150, 2), (70, 200, 3), (33, 97, 1), (64, 64, 1), (100, 300, 4), (31, 150, 2)])
+def test_myers_column_blocks_with_carry_words(oracle, qlen, slen, nwb):
+    """The > 1024 bp scheme at toy scale: blocks of nwb words, carries through per-32-row words."""
+    q, s = _inputs(oracle, 3300 + slen + qlen, 2, 40, qlen, slen)
+    s[0] = ord("A")
+    q[0] = ord("A")                      # carries run through every word and every block
+    want = oracle.myers64(q, s)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.myers_blocked_simulate(s, q[i], nwb), want[i])
+
+
 def test_myers_two_groups_per_wave(oracle):
     q, s = _inputs(oracle, 77, 2, 32, 150, 150)
     nw = 5
@@ -102,7 +113,7 @@ def test_banded_body_and_events_match_oracle(oracle, length, k):
 
 
 def test_emitted_asm_respects_the_vcc_hazard():
-    for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5), R.myers_planes_body(12)):
+    for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5), R.myers_planes_body(12), R.myers_block_body(12)):
         lines = body.emit_asm(lambda name: name)
         since = 99
         for ln in lines:
