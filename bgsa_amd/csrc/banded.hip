@@ -20,7 +20,7 @@
 // test holds at that LAST checkpoint; any earlier test that fires implies it.  A wave therefore
 // tests every 16 rows from the start and stops as soon as all 64 lanes are past the limit.
 //
-// Band of 2k+1 (+1 carry) bits: 32-bit words for k <= 15, 64-bit words for k <= 31; any length.
+// Band of 2k+1 (+1 carry) bits: one 32-bit word for k <= 15, a 64-bit pair for k <= 31; any length.
 // Supported domain: query_len == subject_len (the reference's band is mis-aligned otherwise,
 // SURVEY.md §8(a) A5) — anything else is refused loudly.
 #include <stdlib.h>
@@ -63,27 +63,26 @@ __device__ __forceinline__ void band_row(T win, T &vp, T &vn, uint32_t &acc)
     acc += 1u - static_cast<uint32_t>(d0 & 1);
 }
 
-// Only the first three Mext words per class are register-resident (they serve rows 0..2W-1, which
-// is as far as most waves get on unrelated reads); beyond that the wave re-reads, every W rows,
-// the word the next W windows straddle (5 coalesced loads that hit L1/L2), so the kernel needs
-// ~45 VGPRs at any length.
+// Compiler-scheduled kernel of the same algorithm (A/B reference for the asm kernels, selected by
+// BGSA_BANDED_IMPL=c).  T = band word: uint32_t for k <= 15, uint64_t for k <= 31.  The first four
+// 32-bit Mext words per class are register-resident (rows 0..31 need words 0..2); beyond that the
+// wave re-reads, every 32 rows, the word the next windows straddle.
 template <typename T>
 __global__ __launch_bounds__(256) void banded_kernel(
-    const char *__restrict__ content, const T *__restrict__ mext, int8_t *__restrict__ out,
+    const char *__restrict__ content, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     int len, long long ld, int n_groups, int word_num, int ref_start, int ref_end, int q_tile, int k)
 {
     constexpr int W = BandWord<T>::bits;
     const int lane = threadIdx.x & (kLanes - 1);
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (group >= n_groups) return;
-    const T *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+    const uint32_t *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
 
-    // Words 0..2 of every class stay in registers across the query tile (rows 0 .. 2W-1).
-    T first[kChars][3];
+    uint32_t first[kChars][4];
 #pragma unroll
     for (int c = 0; c < kChars; c++)
 #pragma unroll
-        for (int w = 0; w < 3; w++) first[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : T(0);
+        for (int w = 0; w < 4; w++) first[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
 
     const int h = k;                       // h_threshold = k + n - m with n == m (:70)
     const int band_down = k + h;           // band_length - 1 (:71-72)
@@ -103,31 +102,34 @@ __global__ __launch_bounds__(256) void banded_kernel(
         uint32_t acc = 0;                  // err - k; rows < k do not score (:116-123)
         bool dead = false, all_dead = false;
         UniformBytes qs(content + static_cast<size_t>(q) * (len + 1));
-        T lo[kChars], hi[kChars];
+        uint32_t x0[kChars], x1[kChars], x2[kChars];  // words wi, wi+1, wi+2 of every class
 #pragma unroll
-        for (int c = 0; c < kChars; c++) hi[c] = first[c][0];
+        for (int c = 0; c < kChars; c++) { x1[c] = first[c][0]; x2[c] = first[c][1]; x0[c] = 0u; }
         for (int r = 0; r < len && !all_dead; r++) {
-            const int j = r & (W - 1);
-            if (j == 0) {                  // windows of rows r .. r+W-1 straddle words r/W and r/W+1
-                const int wi = r / W;
+            const int j = r & 31;
+            if (j == 0) {
+                const int wi = r >> 5;
 #pragma unroll
                 for (int c = 0; c < kChars; c++) {
-                    lo[c] = hi[c];
-                    if (wi == 0) hi[c] = first[c][1];          // resident: no memory latency on the
-                    else if (wi == 1) hi[c] = first[c][2];     // rows most waves ever reach
-                    else hi[c] = (wi + 1 < word_num) ? g[(c * word_num + wi + 1) * kLanes] : T(0);
+                    x0[c] = x1[c];
+                    x1[c] = x2[c];
+                    if (wi + 2 < 4) x2[c] = first[c][(wi + 2) & 3];
+                    else x2[c] = (wi + 2 < word_num) ? g[(c * word_num + wi + 2) * kLanes] : 0u;
                 }
             }
             if ((r & 3) == 0) qs.refill(r, len - r);
             const uint32_t c = __builtin_amdgcn_readfirstlane(qs.next());
-            T win;
+            uint32_t a, b, d;
             switch (c) {
-            case 0: win = BandWord<T>::funnel(hi[0], lo[0], j); break;
-            case 1: win = BandWord<T>::funnel(hi[1], lo[1], j); break;
-            case 2: win = BandWord<T>::funnel(hi[2], lo[2], j); break;
-            case 3: win = BandWord<T>::funnel(hi[3], lo[3], j); break;
-            default: win = BandWord<T>::funnel(hi[4], lo[4], j); break;
+            case 0: a = x0[0]; b = x1[0]; d = x2[0]; break;
+            case 1: a = x0[1]; b = x1[1]; d = x2[1]; break;
+            case 2: a = x0[2]; b = x1[2]; d = x2[2]; break;
+            case 3: a = x0[3]; b = x1[3]; d = x2[3]; break;
+            default: a = x0[4]; b = x1[4]; d = x2[4]; break;
             }
+            const uint32_t lo = BandWord<uint32_t>::funnel(b, a, j);
+            T win = lo;
+            if constexpr (W == 64) win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
             if (r == k) acc = 0;           // scoring starts at row k with err = k (:116-134)
             band_row<T>(win & band_mask, vp, vn, acc);
             const int done = r + 1;
@@ -160,28 +162,30 @@ namespace { int banded_impl(); }
 // ---- generated row loop (gen_rows_asm.py: gen_banded_function) -----------------------------------
 #include "banded_rows_gen.inc"
 
-// k <= 15: the whole query runs inside one generated asm block — 12 VALU + ~8 SALU per row, the
-// window advance / checkpoints / early exit driven by EVENT tokens of the packed stream
-// (bgsa_common.h: banded_stream_layout).  Same results as banded_kernel<uint32_t>.
+// The whole query runs inside one generated asm block — 12 VALU per row for k <= 15 (32-bit band
+// word), 22 for k <= 31 (64-bit pair) — with the window advance / checkpoints / early exit driven by
+// EVENT tokens of the packed stream (bgsa_common.h: banded_stream_layout).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void banded_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes)
 {
+    constexpr int NM = WIDE ? 4 : 3;  // resident 32-bit words per class, the last one is the prefetch target
     const int lane = threadIdx.x & (kLanes - 1);
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (group >= n_groups) return;
     const uint32_t *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes;
 
-    uint32_t first[kChars][3];
+    uint32_t first[kChars][NM];
     unsigned long long base[kChars];
 #pragma unroll
     for (int c = 0; c < kChars; c++) {
         base[c] = uniform_u64(reinterpret_cast<unsigned long long>(g + static_cast<size_t>(c) * word_num * kLanes));
 #pragma unroll
-        for (int w = 0; w < 3; w++) first[c][w] = g[(c * word_num + w) * kLanes + lane];
+        for (int w = 0; w < NM; w++) first[c][w] = g[(c * word_num + w) * kLanes + lane];
     }
     const int h = k;
-    const uint32_t band_mask = (1u << (k + h + 1)) - 1u;   // 2k+1 <= 31 bits
+    const unsigned long long band = (k + h + 1 >= 64) ? ~0ull : ((1ull << (k + h + 1)) - 1ull);
     const uint32_t limit = static_cast<uint32_t>(h + 1);   // err > k+h+1  <=>  errors since row k > h+1
 
     const int q0 = blockIdx.y * q_tile;
@@ -189,26 +193,41 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
     int8_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
 
     for (int q = q0; q < q1; q++) {
-        uint32_t st[3] = {0u, 0u, 0u};
-        uint32_t M[kChars][3];
+        uint32_t st[WIDE ? 5 : 3];
+#pragma unroll
+        for (int i = 0; i < (WIDE ? 5 : 3); i++) st[i] = 0u;
+        uint32_t M[kChars][NM];
 #pragma unroll
         for (int c = 0; c < kChars; c++)
 #pragma unroll
-            for (int w = 0; w < 3; w++) M[c][w] = first[c][w];
-        uint32_t voff = static_cast<uint32_t>(lane * 4 + 3 * kLanes * 4);  // word 3 of this lane
+            for (int w = 0; w < NM; w++) M[c][w] = first[c][w];
+        uint32_t voff = static_cast<uint32_t>(lane * 4 + NM * kLanes * 4);  // word NM of this lane
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        const unsigned long long dead_mask =
-            banded_rows_asm(st, M, voff, base, uniform_u64(s),
-                            __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2), band_mask, limit);
+        const int n_windows = __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2);
+        unsigned long long dead_mask;
+        unsigned long long vp, vn;
+        uint32_t acc;
+        if constexpr (WIDE) {
+            dead_mask = banded_rows_asm64(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band),
+                                          static_cast<uint32_t>(band >> 32), limit);
+            vp = st[0] | (static_cast<unsigned long long>(st[1]) << 32);
+            vn = st[2] | (static_cast<unsigned long long>(st[3]) << 32);
+            acc = st[4];
+        } else {
+            dead_mask = banded_rows_asm32(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band), 0u, limit);
+            vp = st[0];
+            vn = st[1];
+            acc = st[2];
+        }
         const bool dead = (dead_mask >> lane) & 1ull;
         int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
         if (dead_mask != ~0ull) {
             // :230-245 — walk the last row across the band, keep the minimum.
-            uint32_t err = static_cast<uint32_t>(k) + st[2], best = err;
+            uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
             for (int i = 0; i <= h; i++) {
-                err += (st[0] >> i) & 1u;
-                err -= (st[1] >> i) & 1u;
+                err += static_cast<uint32_t>((vp >> i) & 1ull);
+                err -= static_cast<uint32_t>((vn >> i) & 1ull);
                 best = err < best ? err : best;
             }
             if (!dead) result = static_cast<int8_t>(best);
@@ -243,9 +262,14 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     }
     if (int rc = launch_pack_banded(d_content, len, k, ref_start, ref_end, d_workspace, stream)) return rc;
     const int stride = banded_stream_layout(len, k, nullptr, nullptr);
-    hipLaunchKernelGGL(banded_asm_kernel, grid, dim3(256), 0, stream, static_cast<const unsigned char *>(d_workspace),
-                       d_peq, d_results, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq,
-                       q_tile, k, stride);
+    if (k <= 15)
+        hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride);
+    else
+        hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -264,8 +288,7 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
         set_error_text("banded: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL((banded_kernel<T>), grid, dim3(256), 0, stream, d_content,
-                       reinterpret_cast<const T *>(d_peq), d_results, len,
+    hipLaunchKernelGGL((banded_kernel<T>), grid, dim3(256), 0, stream, d_content, d_peq, d_results, len,
                        static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, ref_start,
                        ref_end, q_tile, k);
     BGSA_HIP_TRY(hipGetLastError());
@@ -274,11 +297,13 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
 
 }  // namespace
 
+static thread_local int g_last_k = 8;  // threshold of this thread's last banded launch
+
 const char *banded_kernel_name(int word_num)
 {
     (void)word_num;
-    // k <= 15 -> banded_asm_kernel unless BGSA_BANDED_IMPL=c; the C ABI passes word_num only
-    return (threshold <= 15 && banded_impl() == 0) ? "banded_asm_kernel" : "banded_kernel<T>";
+    if (banded_impl() != 0) return g_last_k <= 15 ? "banded_kernel<uint32_t>" : "banded_kernel<uint64_t>";
+    return g_last_k <= 15 ? "banded_asm_kernel<false>" : "banded_asm_kernel<true>";
 }
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
@@ -294,7 +319,8 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
         set_error_text("banded: threshold must satisfy 1 <= k <= 31 and 2k+1 < length");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    if (k <= 15 && banded_impl() == 0)
+    g_last_k = k;
+    if (banded_impl() == 0)
         return launch_asm(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                           d_workspace, stream);
     if (k <= 15)

@@ -120,8 +120,8 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k)
     case BGSA_ALGO_BITPAL: return (subject_len + 31) / 32;  // same layout as Myers
     case BGSA_ALGO_BANDED: {
         (void)query_len;                                     // equal lengths only (banded.hip)
-        const int w = k <= 15 ? 32 : 64;                     // band of 2k+2 bits per word
-        return (subject_len + w - 1) / w + 2;                // + zero words for the funnel shift / prefetch
+        (void)k;
+        return (subject_len + 31) / 32 + 3;                  // + zero words: 64-bit window of the last row, prefetch
     }
     default: return -1;
     }
@@ -129,8 +129,9 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k)
 
 size_t bgsa_hip_group_words(int algo, int word_num, int k)
 {
-    const size_t per = static_cast<size_t>(BGSA_CHAR_NUM) * word_num * HIP_V_NUM;
-    return (algo == BGSA_ALGO_BANDED && k > 15) ? 2 * per : per;
+    (void)algo;
+    (void)k;
+    return static_cast<size_t>(BGSA_CHAR_NUM) * word_num * HIP_V_NUM;
 }
 
 // ---- device-resident layer ---------------------------------------------------------------------

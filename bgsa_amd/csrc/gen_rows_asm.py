@@ -144,16 +144,20 @@ __device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_
 """
 
 
-def gen_banded_function() -> str:
-    """Row loop of the banded kernel (32-bit band words, k <= 15).  Same threaded-code skeleton
-    plus stream code 7 = EVENT (followed by an argument byte): test/latch the reject mask, reset
-    the error count at row k, advance the match-string words every 32 rows (rows_ir.banded_tokens)."""
-    body = R.banded_body()
+def gen_banded_function(wide: bool) -> str:
+    """Row loop of the banded kernel: 32-bit band word (k <= 15) or a 64-bit pair (k <= 31).  Same
+    threaded-code skeleton plus stream code 7 = EVENT (followed by an argument byte): test/latch the
+    reject mask, reset the error count at row k, advance the match-string words every 32 rows
+    (rows_ir.banded_tokens)."""
+    body = R.banded_body64() if wide else R.banded_body()
+    n_state = 5 if wide else 3          # the error count is the last state register
+    n_m = 4 if wide else 3              # resident match-string words per class (last = prefetch target)
+    acc = n_state - 1
     slot_of, n_slots = body.allocate_temps()
-    S_MASK, S_SH, S_ARG, S_THR = "s72", "s73", "s74", "s78"
+    S_MASK, S_SH, S_ARG, S_THR, S_MASK_HI = "s72", "s73", "s74", "s78", "s75"
     S_DEAD, S_TMP = "s[76:77]", "s[90:91]"
     S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
-    clobbers = CLOBBERS[:-3] + ["s72", "s73", "s74", "s76", "s77", "s78"] + [f"s{i}" for i in range(80, 92)] + \
+    clobbers = CLOBBERS[:-3] + ["s72", "s73", "s74", "s75", "s76", "s77", "s78"] + [f"s{i}" for i in range(80, 92)] + \
         ["vcc", "scc", "memory"]
 
     def reg_for(c: int):
@@ -162,8 +166,10 @@ def gen_banded_function() -> str:
                 return f"%[s{name[1:]}]"
             if name.startswith("E"):
                 return f"%[m{name[1:]}_{c}]"
-            if name == "$mask":
+            if name in ("$mask", "$mask_lo"):
                 return S_MASK
+            if name == "$mask_hi":
+                return S_MASK_HI
             if name == "$sh":
                 return S_SH
             if name == "$one":
@@ -180,6 +186,7 @@ def gen_banded_function() -> str:
         f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
         f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
         f"s_mov_b32 {S_MASK}, %[mask]",
+        f"s_mov_b32 {S_MASK_HI}, %[mask_hi]",
         f"s_mov_b32 {S_THR}, %[thr]",
         f"s_mov_b32 {S_SH}, 0",
         f"s_mov_b64 {S_DEAD}, 0",
@@ -221,7 +228,7 @@ def gen_banded_function() -> str:
         # bit 2: test err > limit on every lane; bit 3: latch the reject mask (last checkpoint)
         f"s_bitcmp1_b32 {S_ARG}, 2",
         "s_cbranch_scc0 L_ev_reset_%=",
-        f"v_cmp_lt_u32 vcc, {S_THR}, %[s2]",
+        f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc}]",
         f"s_bitcmp1_b32 {S_ARG}, 3",
         "s_cbranch_scc0 L_ev_all_%=",
         f"s_mov_b64 {S_DEAD}, vcc",
@@ -233,16 +240,16 @@ def gen_banded_function() -> str:
         "L_ev_reset_%=:",
         f"s_bitcmp1_b32 {S_ARG}, 0",      # bit 0: scoring starts (row k)
         "s_cbranch_scc0 L_ev_adv_%=",
-        "v_mov_b32 %[s2], 0",
+        f"v_mov_b32 %[s{acc}], 0",
         "L_ev_adv_%=:",
         f"s_bitcmp1_b32 {S_ARG}, 1",      # bit 1: next 32 rows -> shift the match-string words down
         "s_cbranch_scc0 L_ev_out_%=",
         "s_waitcnt vmcnt(0)",
     ]
     for c in range(5):
-        asm += [f"v_mov_b32 %[m0_{c}], %[m1_{c}]", f"v_mov_b32 %[m1_{c}], %[m2_{c}]"]
+        asm += [f"v_mov_b32 %[m{w}_{c}], %[m{w + 1}_{c}]" for w in range(n_m - 1)]
     for c in range(5):
-        asm.append(f"global_load_dword %[m2_{c}], %[voff], {S_BASE[c]}")
+        asm.append(f"global_load_dword %[m{n_m - 1}_{c}], %[voff], {S_BASE[c]}")
     asm += [
         "v_add_u32 %[voff], 0x100, %[voff]",
         f"s_mov_b32 {S_SH}, 0",
@@ -254,23 +261,25 @@ def gen_banded_function() -> str:
     asm.append(f"s_mov_b64 %[dead], {S_DEAD}")
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
-    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(3)]
-    outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(3)]
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(n_m)]
     outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[mask] "s"(band_mask)', '[thr] "s"(limit)']
+    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[mask] "s"(band_mask)', '[mask_hi] "s"(band_mask_hi)',
+           '[thr] "s"(limit)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
     clob = ", ".join(f'"{x}"' for x in clobbers)
     return f"""
 // {body.valu_count()} VALU per row ({sum(op.kind in ('lshr1', 'alignbit') for op in body.ops)} of them slow-class), {n_slots} temporaries
-// state = {{VP, VN, errors since row k}}; M[c][0..2] = three consecutive words of class c's offset
-// match string (word 2 is the prefetch target); voff = byte offset of the next word to fetch
-// relative to base[c]; returns the reject mask (lanes whose error count passed `limit` at the last
-// checkpoint, or all lanes if the wave stopped early).
-__device__ __forceinline__ unsigned long long banded_rows_asm(uint32_t (&state)[3], uint32_t (&M)[5][3], uint32_t &voff,
+// state = {{VP, VN, errors since row k}} (VP lo/hi, VN lo/hi, errors when wide); M[c][..] = consecutive
+// 32-bit words of class c's offset match string (the last one is the prefetch target); voff = byte
+// offset of the next word to fetch relative to base[c]; returns the reject mask (lanes whose error
+// count passed `limit` at the last checkpoint, or all lanes if the wave stopped early).
+__device__ __forceinline__ unsigned long long banded_rows_asm{64 if wide else 32}(uint32_t (&state)[{n_state}], uint32_t (&M)[5][{n_m}], uint32_t &voff,
                                                               const unsigned long long (&base)[5],
                                                               const unsigned long long stream, const int n_windows,
-                                                              const uint32_t band_mask, const uint32_t limit)
+                                                              const uint32_t band_mask, const uint32_t band_mask_hi,
+                                                              const uint32_t limit)
 {{
     uint32_t tmp[{max(n_slots, 1)}];
     unsigned long long dead;
@@ -416,7 +425,7 @@ def main() -> int:
         parts.append(gen_function("bitpal_rows_asm", f"{nw}", R.bitpal_body(nw), 5 * nw, nw))
     (here / "bitpal_rows_gen.inc").write_text("".join(parts))
     # ---- banded -------------------------------------------------------------------------------
-    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function())
+    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(True))
     return 0
 
 

@@ -9,8 +9,7 @@
 //     peq[group][char 0..4][word 0..word_num-1][lane 0..63]
 // Global Myers / BitPAl: 32-bit words, bit (p mod D) of word (p div D) set iff subject[p] maps to
 // `char`, D = 32 data bits per word (the reference keeps one bit per word as a software carry).
-// Banded: the match bit-string offset by k+1 zero bits, 32-bit words for k <= 15 and 64-bit above
-// (see "banded layout" below).
+// Banded: the match bit-string offset by k+1 zero bits, 32-bit words (see "banded layout" below).
 #include <algorithm>
 #include <thread>
 #include <vector>
@@ -102,32 +101,29 @@ __global__ __launch_bounds__(256) void preprocess_global_lds_kernel(const char *
 
 // ---- banded layout ------------------------------------------------------------------------------
 // "Mext": per character class, the subject's match bit-string offset by k+1 zero bits — bit i is
-// set iff i >= k+1 and subject[i-(k+1)] maps to the class.  Words 0 of the reference's layout
-// (first k characters at bits k+1..2k, banded/BGSA_CPU/global.c:45-62) is Mext bits 0..2k, and its
-// per-row shift-and-feed (align_core.c:35-62) walks the same string one bit per row, so the
-// window the reference holds at row r is Mext bits r .. r+2k (banded.hip).  Word width W = 32 for
-// k <= 15, 64 above; word_num = ceil(len / W) + 1 (one spare zero word for the funnel shift).
-template <typename T>
+// set iff i >= k+1 and subject[i-(k+1)] maps to the class — in 32-bit words.  Word 0 of the
+// reference's layout (first k characters at bits k+1..2k, banded/BGSA_CPU/global.c:45-62) is Mext
+// bits 0..2k, and its per-row shift-and-feed (align_core.c:35-62) walks the same string one bit per
+// row, so the window the reference holds at row r is Mext bits r .. r+2k (banded.hip).
+// word_num = ceil(len / 32) + 3: the 64-bit window of the last row and the prefetch stay in bounds.
 __global__ __launch_bounds__(256) void preprocess_banded_kernel(const char *__restrict__ rows,
-                                                                T *__restrict__ mext, int len,
-                                                                long long read_count, int word_num,
-                                                                int k)
+                                                                uint32_t *__restrict__ mext, int len,
+                                                                long long read_count, int word_num, int k)
 {
-    constexpr int W = sizeof(T) * 8;
     const long long subject = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (subject >= read_count) return;
     const long long group = subject >> 6;
     const int lane = static_cast<int>(subject & 63);
     const char *row = rows + subject * (len + 1);
-    T *dst = mext + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+    uint32_t *dst = mext + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
     for (int w = 0; w < word_num; w++) {
-        T m[kChars] = {0, 0, 0, 0, 0};
-        for (int b = 0; b < W; b++) {
-            const int p = w * W + b - (k + 1);
+        uint32_t m[kChars] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < 32; b++) {
+            const int p = w * 32 + b - (k + 1);
             if (p < 0 || p >= len) continue;
             const uint32_t c = map_char(static_cast<uint8_t>(row[p]));
 #pragma unroll
-            for (uint32_t cc = 0; cc < kChars; cc++) m[cc] |= static_cast<T>(c == cc) << b;
+            for (uint32_t cc = 0; cc < kChars; cc++) m[cc] |= static_cast<uint32_t>(c == cc) << b;
         }
 #pragma unroll
         for (int cc = 0; cc < kChars; cc++) dst[(cc * word_num + w) * kLanes] = m[cc];
@@ -225,13 +221,9 @@ int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len
 {
     if (read_count == 0) return BGSA_HIP_OK;
     const unsigned blocks = static_cast<unsigned>((read_count + 255) / 256);
-    if (algo == BGSA_ALGO_BANDED && k <= 15) {
-        hipLaunchKernelGGL(preprocess_banded_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, d_rows,
-                           d_peq, len, static_cast<long long>(read_count), word_num, k);
-    } else if (algo == BGSA_ALGO_BANDED) {
-        hipLaunchKernelGGL(preprocess_banded_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, d_rows,
-                           reinterpret_cast<uint64_t *>(d_peq), len, static_cast<long long>(read_count),
-                           word_num, k);
+    if (algo == BGSA_ALGO_BANDED) {
+        hipLaunchKernelGGL(preprocess_banded_kernel, dim3(blocks), dim3(256), 0, stream, d_rows, d_peq, len,
+                           static_cast<long long>(read_count), word_num, k);
     } else if (64 * (len + 1) + 32 <= 16 * 1024 && (reinterpret_cast<uintptr_t>(d_rows) & 15) == 0 &&
                avail_bytes >= read_count * (len + 1)) {
         const long long n_groups = read_count / kLanes;
@@ -271,13 +263,12 @@ void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint3
                 const int64_t off = (g * kLanes + lane) * static_cast<int64_t>(len + 1);
                 const char *row = rows + off;
                 if (algo == BGSA_ALGO_BANDED) {
-                    const int W = k <= 15 ? 32 : 64;
                     const size_t base = static_cast<size_t>(g) * kChars * word_num * kLanes + lane;
                     for (int p = 0; p < len; p++) {
                         const int i = p + k + 1;  // Mext bit index
-                        const size_t idx = base + (static_cast<size_t>(map_char(static_cast<uint8_t>(row[p]))) * word_num + i / W) * kLanes;
-                        if (W == 32) result_reads[idx] |= 1u << (i % 32);
-                        else reinterpret_cast<uint64_t *>(result_reads)[idx] |= 1ULL << (i % 64);
+                        if (i / 32 >= word_num) break;
+                        result_reads[base + (static_cast<size_t>(map_char(static_cast<uint8_t>(row[p]))) * word_num + i / 32) * kLanes] |=
+                            1u << (i % 32);
                     }
                 } else {
                     const int bits = 32;

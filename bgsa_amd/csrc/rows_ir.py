@@ -414,6 +414,36 @@ def banded_body() -> Body:
     return b
 
 
+def banded_body64() -> Body:
+    """64-bit band (16 <= k <= 31) as register pairs.  State: S0/S1 = VP lo/hi, S2/S3 = VN lo/hi,
+    S4 = errors since row k.  E0..E2 = three consecutive 32-bit words of the class match string;
+    scalars $sh, $mask_lo, $mask_hi, $one.  22 VALU per row, four of them slow class."""
+    b = Body()
+    b.ALIGNBIT("wl", "E1", "E0", "$sh")
+    b.ALIGNBIT("wh", "E2", "E1", "$sh")
+    b.BITOP3("xl", "wl", "$mask_lo", "S2", lambda w, m, vn: (w & m) | vn)
+    b.BITOP3("xh", "wh", "$mask_hi", "S3", lambda w, m, vn: (w & m) | vn)
+    b.AND("tl", "xl", "S0")
+    b.AND("th", "xh", "S1")
+    b.ADD_CO("tl", "tl", "S0")
+    b.ADDC("th", "th", "S1")
+    b.BITOP3("dl", "tl", "S0", "xl", lambda t_, vp, x: (t_ ^ vp) | x)
+    b.BITOP3("dh", "th", "S1", "xh", lambda t_, vp, x: (t_ ^ vp) | x)
+    b.BITOP3("hpl", "dl", "S0", "S2", lambda d, vp, vn: ~(d | vp) | vn)
+    b.BITOP3("hph", "dh", "S1", "S3", lambda d, vp, vn: ~(d | vp) | vn)
+    b.AND("hnl", "dl", "S0")
+    b.AND("hnh", "dh", "S1")
+    b.ALIGNBIT("x2l", "dh", "dl", "$one")      # (D0 >> 1) low word
+    b.LSHR1("x2h", "dh")
+    b.AND("S2", "x2l", "hpl")
+    b.AND("S3", "x2h", "hph")
+    b.BITOP3("S0", "hpl", "x2l", "hnl", lambda hp, x2, hn: ~(hp | x2) | hn)
+    b.BITOP3("S1", "hph", "x2h", "hnh", lambda hp, x2, hn: ~(hp | x2) | hn)
+    b.BITOP3("e", "dl", "$one", "$one", lambda d, one, _o: ~d & one)
+    b.ADD("S4", "S4", "e")
+    return b
+
+
 def banded_last_check(length: int, k: int) -> int:
     """Rows after which the reference runs its last err > max_err test (banded.hip)."""
     h = k
@@ -444,9 +474,14 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
     return out
 
 
-def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int) -> np.ndarray:
+def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool | None = None) -> np.ndarray:
     """Whole banded pipeline on the CPU with the shipped row body: Mext preprocess, token
-    stream, events, final band walk.  Returns int8 results like the kernel."""
+    stream, events, final band walk.  Returns int8 results like the kernel.  wide = the 64-bit
+    band body (register pairs), the default for k > 15."""
+    if wide is None:
+        wide = k > 15
+    if wide:
+        return _banded_simulate64(subjects, query, k)
     n, length = subjects.shape
     code = np.zeros(256, dtype=np.uint8)
     for ch, c in zip(b"ACGTN", range(5)):
@@ -486,6 +521,53 @@ def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int) -> np.ndarr
     best = err.copy()
     for i in range(h + 1):
         err = err + ((st[0] >> np.uint32(i)) & 1) - ((st[1] >> np.uint32(i)) & 1)
+        best = np.minimum(best, err)
+    return np.where(dead, 127, best).astype(np.int8)
+
+
+def _banded_simulate64(subjects: np.ndarray, query: np.ndarray, k: int) -> np.ndarray:
+    n, length = subjects.shape
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, c in zip(b"ACGTN", range(5)):
+        code[ch] = c
+    mapped = code[subjects]
+    nwords = (length + 31) // 32 + 3
+    mext = np.zeros((5, nwords, n), dtype=np.uint32)
+    for p in range(length):
+        i = p + k + 1
+        for c in range(5):
+            mext[c, i // 32] |= (mapped[:, p] == c).astype(np.uint32) << np.uint32(i % 32)
+    h = k
+    band = (1 << (2 * k + 1)) - 1
+    body = banded_body64()
+    st = [np.zeros(n, dtype=np.uint32) for _ in range(5)]
+    dead = np.zeros(n, dtype=bool)
+    wi, sh = 0, 0
+    qcode = code[query]
+    for kind, val in banded_tokens(length, k):
+        if kind == "event":
+            if val & 4:
+                over = st[4] > np.uint32(h + 1)
+                if val & 8:
+                    dead = over.copy()
+                if over.all():
+                    dead[:] = True
+                    break
+            if val & 1:
+                st[4] = np.zeros(n, dtype=np.uint32)
+            if val & 2:
+                wi, sh = wi + 1, 0
+        else:
+            c = int(qcode[val])
+            body.simulate(st, [mext[c, wi], mext[c, wi + 1], mext[c, wi + 2]],
+                          scalars={"$sh": sh, "$mask_lo": band & 0xFFFFFFFF, "$mask_hi": band >> 32, "$one": 1})
+            sh += 1
+    vp = st[0].astype(np.uint64) | (st[1].astype(np.uint64) << np.uint64(32))
+    vn = st[2].astype(np.uint64) | (st[3].astype(np.uint64) << np.uint64(32))
+    err = st[4].astype(np.int64) + k
+    best = err.copy()
+    for i in range(h + 1):
+        err = err + ((vp >> np.uint64(i)) & np.uint64(1)).astype(np.int64) - ((vn >> np.uint64(i)) & np.uint64(1)).astype(np.int64)
         best = np.minimum(best, err)
     return np.where(dead, 127, best).astype(np.int8)
 

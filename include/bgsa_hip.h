@@ -34,7 +34,7 @@ extern "C" {
 #define BGSA_CHAR_NUM 5            /* CHAR_NUM: A C G T N planes */
 #define HIP_V_NUM 64               /* subjects per group = lanes of one wavefront */
 #define HIP_WORD_SIZE 32           /* bits per bit-vector word; all 32 carry data (full_bits = 1) */
-#define HIP_BANDED_WORD_SIZE 64    /* widest banded window (k <= 31); 32-bit words when k <= 15 */
+#define HIP_BANDED_WORD_SIZE 64    /* widest banded window (k <= 31), as in the reference */
 #define HIP_MAX_ERROR 127          /* MAX_ERROR, banded/BGSA_CPU/config.h:19 */
 typedef uint32_t hip_read_t;       /* element of the preprocessed Peq blocks */
 typedef uint32_t hip_data_t;       /* element of the (unused) dvdh_bit_mem scratch */
@@ -89,8 +89,7 @@ int bgsa_hip_current_algorithm(void);
 /* word_num for the selected algorithm (what cal_<arch>.c computes at cal_cpu.c:252-256, banded
  * cal_cpu.c:253-254). */
 int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k);
-/* hip_read_t elements per group of HIP_V_NUM subjects = BGSA_CHAR_NUM * word_num * HIP_V_NUM,
- * doubled for the banded layout with k > 15 (64-bit words). */
+/* hip_read_t elements per group of HIP_V_NUM subjects = BGSA_CHAR_NUM * word_num * HIP_V_NUM. */
 size_t bgsa_hip_group_words(int algo, int word_num, int k);
 
 /* ---- BGSA backend surface (host buffers) --------------------------------------------------- */

@@ -43,11 +43,11 @@ def test_word_num(L):
     assert B.word_num(B.ALGO_MYERS, 150, 150) == 5
     assert B.word_num(B.ALGO_MYERS, 1000, 1000) == 32
     assert B.word_num(B.ALGO_MYERS, 1, 32) == 1 and B.word_num(B.ALGO_MYERS, 1, 33) == 2
-    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 7   # 32-bit words of the offset match string + 2 spare
-    assert B.word_num(B.ALGO_BANDED, 150, 150, 16) == 5  # 64-bit words above k = 15
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 8) == 8   # 32-bit words of the offset match string + 3 spare
+    assert B.word_num(B.ALGO_BANDED, 150, 150, 16) == 8  # same layout for the 64-bit band
     assert B.group_words(B.ALGO_MYERS, 5) == 5 * 5 * 64
-    assert B.group_words(B.ALGO_BANDED, 6, 8) == 5 * 6 * 64
-    assert B.group_words(B.ALGO_BANDED, 4, 16) == 2 * 5 * 4 * 64
+    assert B.group_words(B.ALGO_BANDED, 8, 8) == 5 * 8 * 64
+    assert B.group_words(B.ALGO_BANDED, 8, 16) == 5 * 8 * 64
 
 
 def test_mapping_table(L):
@@ -92,17 +92,17 @@ def test_host_handle_reads_layout_myers(L, oracle):
 
 
 def test_host_handle_reads_layout_banded(L, oracle):
-    # Mext: bit i of plane c is set iff i >= k+1 and subject[i-(k+1)] == c (32-bit words, k <= 15)
+    # Mext: bit i of plane c is set iff i >= k+1 and subject[i-(k+1)] == c, 32-bit words for every k
     rows = oracle.gen_reads(78, 64, 150)
-    for k, dtype, W in ((8, np.uint32, 32), (16, np.uint64, 64)):
+    for k in (8, 16, 31):
         padded, peq, wn = _host_preprocess(L, B.ALGO_BANDED, rows, k=k)
-        assert wn == (150 + W - 1) // W + 2
-        peq = peq.view(dtype).reshape(-1, 5, wn, 64)
+        assert wn == (150 + 31) // 32 + 3
+        peq = peq.reshape(-1, 5, wn, 64)
         s = 5
         for p in range(150):
             i = p + k + 1
             for cc in range(5):
-                bit = (int(peq[0, cc, i // W, s]) >> (i % W)) & 1
+                bit = (int(peq[0, cc, i // 32, s]) >> (i % 32)) & 1
                 assert bit == (cc == CODE[padded[s, p]])
         assert int(np.bitwise_count(peq[0, :, :, s]).sum()) == 150
 

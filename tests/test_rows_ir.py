@@ -102,7 +102,8 @@ def test_bitpal_body_on_golden_specials(oracle):
         assert np.array_equal(R.bitpal_score(st, nw, 150, 150), g["scores"][i])
 
 
-@pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (150, 15), (64, 8), (65, 8), (100, 12), (200, 8)])
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (150, 15), (64, 8), (65, 8), (100, 12), (200, 8),
+                                      (150, 16), (150, 31), (100, 25), (250, 20), (70, 31)])
 def test_banded_body_and_events_match_oracle(oracle, length, k):
     q = oracle.gen_reads(2500 + length + k, 4, length)
     s = oracle.gen_reads(2600 + length + k, 96, length)
