@@ -155,15 +155,15 @@ int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
 const char *bitpal_kernel_name(int word_num);
 
 // long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.
-inline bool needs_long_kernel(int algo, int word_num)
+inline bool beyond_registers(int algo, int word_num)
 {
-    return algo == BGSA_ALGO_BITPAL && word_num > 8;  // Myers > 1024 bp: column blocks (myers_global.hip)
+    return (algo == BGSA_ALGO_MYERS && word_num > kMaxWords) || (algo == BGSA_ALGO_BITPAL && word_num > 8);
 }
 // Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.
 constexpr int kBlockedBlocks = 512;  // persistent workgroups of myers_blocked_kernel
-inline size_t blocked_carry_bytes(int ref_len)
+inline size_t blocked_carry_bytes(int ref_len, int n_chains)
 {
-    return static_cast<size_t>((ref_len + 31) / 32) * 3 * kLanes * sizeof(uint32_t) * kWavesPerBlock * kBlockedBlocks;
+    return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * kBlockedBlocks;
 }
 size_t long_state_bytes(int algo, int word_num);
 int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,

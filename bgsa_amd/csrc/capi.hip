@@ -217,11 +217,11 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream)
 size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries)
 {
     if (ref_len <= 0 || n_queries <= 0) return 0;
-    if (read_len > 0 && needs_long_kernel(algo, (read_len + 31) / 32)) return long_state_bytes(algo, (read_len + 31) / 32);
-    if (algo == BGSA_ALGO_MYERS && (read_len + 31) / 32 > kMaxWords) {  // column blocks: streams + carry buffers
+    if (read_len > 0 && beyond_registers(algo, (read_len + 31) / 32)) {  // column blocks: streams + carry buffers
+        const int chains = algo == BGSA_ALGO_BITPAL ? 13 : 3;
         const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
-                               blocked_carry_bytes(ref_len);
-        const size_t in_memory = long_state_bytes(algo, (read_len + 31) / 32);  // BGSA_MYERS_IMPL=c
+                               blocked_carry_bytes(ref_len, chains);
+        const size_t in_memory = long_state_bytes(algo, (read_len + 31) / 32);  // BGSA_*_IMPL=c
         return blocked > in_memory ? blocked : in_memory;
     }
     if (algo == BGSA_ALGO_BANDED)  // event tokens make the stream longer; k = 1 is the longest

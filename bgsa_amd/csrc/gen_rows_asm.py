@@ -35,6 +35,7 @@ MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8]
 MYERS_PLANES_NW = [12, 16, 20, 24, 28, 32]
 MYERS_BLOCK_NW = [20, 24, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
 BITPAL_NW = [1, 2, 3, 4, 5, 6, 7, 8]
+BITPAL_BLOCK_NW = [5, 6, 7, 8]  # block widths of the > 256 bp kernel
 
 # Scalar scratch registers, hard-coded and declared as clobbers (inline asm cannot name the
 # halves of a 64-bit "s" operand, and the jump needs lo/hi arithmetic).
@@ -293,16 +294,16 @@ __device__ __forceinline__ unsigned long long banded_rows_asm{64 if wide else 32
 """
 
 
-def gen_blocked_function(nw: int) -> str:
-    """Row loop of myers_blocked_kernel<NW>: one column block of a long subject.  Stream code 7
-    (no argument) every 32 rows = CARRY: store the three carry-out words of the finished 32 rows
-    to the wave's carry buffer, fetch the three carry-in words of the next 32 rows."""
-    body = R.myers_block_body(nw)
+def gen_blocked_function(fn_name: str, nw: int, body: R.Body, n_base: int, n_chains: int, n_planes: int, n_eq: int) -> str:
+    """Row loop of a column-block kernel: one block of a long subject.  Stream code 7 (no
+    argument) every 32 rows = CARRY: store the carry-out words of the finished 32 rows to the
+    wave's carry buffer, fetch the carry-in words of the next 32 rows.  State = n_base block
+    registers, then n_chains carry-in words, then n_chains carry-out words."""
     slot_of, n_slots = body.allocate_temps()
     S_CB = "s[80:81]"
     clobbers = CLOBBERS[:-3] + ["s80", "s81", "vcc", "scc", "memory"]
-    cin = [2 * nw + i for i in range(3)]
-    cout = [2 * nw + 3 + i for i in range(3)]
+    cin = [n_base + i for i in range(n_chains)]
+    cout = [n_base + n_chains + i for i in range(n_chains)]
 
     def reg_for(c: int):
         def reg(name: str) -> str:
@@ -310,6 +311,8 @@ def gen_blocked_function(nw: int) -> str:
                 return f"%[s{name[1:]}]"
             if name.startswith("B"):
                 return f"%[b{name[1:]}]"
+            if name.startswith("E"):
+                return f"%[e{c}_{name[1:]}]"
             return f"%[t{slot_of[name]}]"
         return reg
 
@@ -346,28 +349,33 @@ def gen_blocked_function(nw: int) -> str:
     asm += dispatch()
     asm.append("L_refill_end_%=:")
     asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
-    asm.append("L_body7_%=:")  # CARRY: chunk j out, chunk j+1 in ([chunk][3][64 lanes] dwords)
-    asm += [f"global_store_dword %[voff], %[s{cout[i]}], {S_CB} offset:{256 * i}" for i in range(3)]
-    asm.append("v_add_u32 %[voff], 0x300, %[voff]")
-    asm += [f"global_load_dword %[s{cin[i]}], %[voff], {S_CB} offset:{256 * i} sc1" for i in range(3)]
+    asm.append(f"L_body7_%=:")  # CARRY: chunk j out, chunk j+1 in ([chunk][chain][64 lanes] dwords)
+    asm += [f"global_store_dword %[voff], %[s{cout[i]}], {S_CB} offset:{256 * i}" for i in range(n_chains)]
+    asm.append(f"v_add_u32 %[voff], 0x{256 * n_chains:x}, %[voff]")
+    asm += [f"global_load_dword %[s{cin[i]}], %[voff], {S_CB} offset:{256 * i} sc1" for i in range(n_chains)]
     asm.append("s_waitcnt vmcnt(0)")
     asm += dispatch()
     asm.append("L_done_%=:")
     asm.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
-    n_state = 2 * nw + 6
+    n_state = n_base + 2 * n_chains
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
     outs += ['[voff] "+v"(voff)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = [f'[b{j}] "v"(B[{j}])' for j in range(3 * nw)]
+    if n_planes:
+        ins = [f'[b{j}] "v"(B[{j}])' for j in range(n_planes)]
+        masks_param = f"const uint32_t (&B)[{n_planes}]"
+    else:
+        ins = [f'[e{c}_{j}] "v"(P[{c}][{j}])' for c in range(5) for j in range(n_eq)]
+        masks_param = f"const uint32_t (&P)[5][{n_eq}]"
     ins += ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[cbase] "s"(carry_base)']
     clob = ", ".join(f'"{x}"' for x in clobbers)
     nops = sum(line.startswith("s_nop") for line in body.emit_asm(lambda x: x, 0))
     return f"""
-// {body.valu_count()} VALU per row, {n_slots} temporaries, {nops} hazard nops
+// {body.valu_count()} VALU per row, {n_slots} temporaries, {n_chains} carry chains, {nops} hazard nops
 template <>
-__device__ __forceinline__ void myers_block_rows_asm<{nw}>(uint32_t (&state)[{n_state}], const uint32_t (&B)[{3 * nw}],
+__device__ __forceinline__ void {fn_name}<{nw}>(uint32_t (&state)[{n_state}], {masks_param},
                                                        uint32_t &voff, const unsigned long long carry_base,
                                                        const unsigned long long stream, const int n_windows)
 {{
@@ -411,7 +419,7 @@ def main() -> int:
                  "                                                     uint32_t &voff, const unsigned long long carry_base,\n"
                  "                                                     const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_BLOCK_NW:
-        parts.append(gen_blocked_function(nw))
+        parts.append(gen_blocked_function("myers_block_rows_asm", nw, R.myers_block_body(nw), 2 * nw, 3, 3 * nw, 0))
     (here / "myers_rows_gen.inc").write_text("".join(parts))
     # ---- BitPAl -------------------------------------------------------------------------------
     parts = [head,
@@ -423,6 +431,19 @@ def main() -> int:
              "                                                const unsigned long long stream, const int n_windows);\n"]
     for nw in BITPAL_NW:
         parts.append(gen_function("bitpal_rows_asm", f"{nw}", R.bitpal_body(nw), 5 * nw, nw))
+    parts.append("\n// One column block of a subject longer than 256 bp (rows_ir.py: make_blocked(bitpal_body)).\n"
+                 "// state = 5 planes x NW, then 13 carry-in words, then 13 carry-out words; voff / carry_base as\n"
+                 "// in myers_block_rows_asm ([32-row chunk][13 chains][64 lanes] dwords).\n"
+                 f"constexpr int kBitpalChains = {len(R.make_blocked(R.bitpal_body(1), 5)[1])};\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ void bitpal_block_rows_asm(uint32_t (&state)[5 * NW + 2 * kBitpalChains],\n"
+                 "                                                      const uint32_t (&P)[5][NW], uint32_t &voff,\n"
+                 "                                                      const unsigned long long carry_base,\n"
+                 "                                                      const unsigned long long stream, const int n_windows);\n")
+    for nw in BITPAL_BLOCK_NW:
+        blocked, init = R.make_blocked(R.bitpal_body(nw), 5 * nw)
+        assert not any(init)  # every BitPAl chain starts with carry-in 0
+        parts.append(gen_blocked_function("bitpal_block_rows_asm", nw, blocked, 5 * nw, len(init), 0, nw))
     (here / "bitpal_rows_gen.inc").write_text("".join(parts))
     # ---- banded -------------------------------------------------------------------------------
     (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(True))

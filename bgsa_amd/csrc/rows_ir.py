@@ -695,6 +695,81 @@ def bitpal_body(nw: int) -> Body:
     return b
 
 
+def make_blocked(body: Body, n_state: int):
+    """Column-block form of a row body: every carry chain enters and leaves through a carry word
+    (32 rows per word, first row in bit 31).  Chain k reads its carry-in with `x + x` on state
+    register S[n_state + k] (VCC = next row's bit) and appends its carry-out with `x + x + vcc` on
+    S[n_state + n_chains + k].  Returns (new body, initial carry-in bit per chain): a chain that
+    started with SETC1 has carry-in 1 in the first block, the others 0.
+    (myers_block_body is this transformation of myers_planes_body, written out by hand.)"""
+    chains = []          # (index of the chain's first op, initial carry)
+    for i, op in enumerate(body.ops):
+        if op.kind == "add_co":
+            chains.append((i, 0))
+        elif op.kind == "setc1":
+            chains.append((i, 1))
+    n = len(chains)
+    starts = {i: k for k, (i, _) in enumerate(chains)}
+    out = Body()
+    open_chain = None
+    for i, op in enumerate(body.ops):
+        if i in starts:
+            if open_chain is not None:
+                out.ADDC(f"S{n_state + n + open_chain}", f"S{n_state + n + open_chain}", f"S{n_state + n + open_chain}")
+            k = starts[i]
+            cin = f"S{n_state + k}"
+            out.ADD_CO(cin, cin, cin)
+            open_chain = k
+            if op.kind == "add_co":
+                out.ops.append(Op("addc", op.dst, op.srcs, 0))
+            continue  # setc1 itself is dropped: the carry-in word supplies the 1
+        out.ops.append(op)
+    if open_chain is not None:
+        out.ADDC(f"S{n_state + n + open_chain}", f"S{n_state + n + open_chain}", f"S{n_state + n + open_chain}")
+    return out, [c for _, c in chains]
+
+
+def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int) -> np.ndarray:
+    """BitPAl over column blocks of nw_block words with carry words between blocks — the scheme of
+    bitpal_blocked_kernel at toy scale.  Returns int16."""
+    n, slen = subjects.shape
+    qlen = len(query)
+    nw_total = (slen + 31) // 32
+    n_blocks = (nw_total + nw_block - 1) // nw_block
+    peq = build_peq32(subjects, n_blocks * nw_block)
+    body, init = make_blocked(bitpal_body(nw_block), 5 * nw_block)
+    n_ch = len(init)
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+    n_chunks = (qlen + 31) // 32
+    FULL = np.uint32(0xFFFFFFFF)
+    carry = [[np.full(n, FULL if init[k] else 0, np.uint32) for k in range(n_ch)] for _ in range(n_chunks)]
+    score = np.full(n, -5 * qlen - 5 * slen, dtype=np.int64)
+    weights = (-1, -2, -4, -8, 16)
+    base = 5 * nw_block
+    for blk in range(n_blocks):
+        st = [np.zeros(n, np.uint32) for _ in range(base)] + [c.copy() for c in carry[0]] + \
+             [np.zeros(n, np.uint32) for _ in range(n_ch)]
+        for r, ch in enumerate(query):
+            if r > 0 and r % 32 == 0:
+                j = r // 32
+                carry[j - 1] = [st[base + n_ch + k].copy() for k in range(n_ch)]
+                for k in range(n_ch):
+                    st[base + k] = carry[j][k].copy()
+            c = code.get(int(ch), 0)
+            body.simulate(st, [peq[c, blk * nw_block + w] for w in range(nw_block)])
+        tail = qlen % 32
+        last = [st[base + n_ch + k] for k in range(n_ch)]
+        if tail:
+            last = [x << np.uint32(32 - tail) for x in last]
+        carry[n_chunks - 1] = [x.copy() for x in last]
+        for w in range(nw_block):
+            rem = slen - 32 * (blk * nw_block + w)
+            mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
+            for i, wt in enumerate(weights):
+                score += wt * np.bitwise_count(st[w * 5 + i] & mask).astype(np.int64)
+    return score.astype(np.int16)
+
+
 def bitpal_init_state(nw: int, lanes: int) -> list:
     return [np.zeros(lanes, dtype=np.uint32) for _ in range(5 * nw)]  # all dH = -5 (:167-171)
 

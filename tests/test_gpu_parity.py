@@ -88,10 +88,11 @@ def test_banded_refuses_unequal_lengths(oracle):
 
 @pytest.mark.parametrize("algo,qlen,slen", [(B.ALGO_MYERS, 1025, 1025), (B.ALGO_MYERS, 300, 2500), (B.ALGO_MYERS, 4000, 4000),
                                             (B.ALGO_MYERS, 31, 1100), (B.ALGO_MYERS, 64, 2049), (B.ALGO_MYERS, 97, 3300),
-                                            (B.ALGO_BITPAL, 257, 257), (B.ALGO_BITPAL, 500, 1000), (B.ALGO_BITPAL, 90, 300)])
+                                            (B.ALGO_BITPAL, 257, 257), (B.ALGO_BITPAL, 500, 1000), (B.ALGO_BITPAL, 90, 300),
+                                            (B.ALGO_BITPAL, 31, 320), (B.ALGO_BITPAL, 64, 513), (B.ALGO_BITPAL, 33, 2000)])
 def test_beyond_register_limits(oracle, algo, qlen, slen):
-    # Myers > 1024 bp: column blocks with carry words (myers_blocked_kernel); BitPAl > 256 bp: the
-    # state-in-memory kernel (long_kernels.hip)
+    # Myers > 1024 bp / BitPAl > 256 bp: column blocks with carry words between blocks
+    # (myers_blocked_kernel, bitpal_blocked_kernel)
     q = oracle.gen_reads(8000 + qlen, 3, qlen)
     s = oracle.gen_reads(9000 + slen, 130, slen)
     m = min(qlen, slen)

@@ -65,6 +65,34 @@ def test_myers_column_blocks_with_carry_words(oracle, qlen, slen, nwb):
         assert np.array_equal(R.myers_blocked_simulate(s, q[i], nwb), want[i])
 
 
+@pytest.mark.parametrize("qlen,slen,nwb", [(150, 150, 2), (70, 200, 3), (33, 97, 1), (64, 64, 1), (40, 300, 4)])
+def test_bitpal_column_blocks_with_carry_words(oracle, qlen, slen, nwb):
+    q, s = _inputs(oracle, 4400 + slen + qlen, 2, 40, qlen, slen)
+    s[0] = ord("A")
+    q[0] = ord("A")
+    want = oracle.bitpal(q, s)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.bitpal_blocked_simulate(s, q[i], nwb), want[i])
+
+
+def test_make_blocked_agrees_with_the_hand_written_myers_block_body():
+    nw = 3
+    auto, init = R.make_blocked(R.myers_planes_body(nw), 2 * nw)
+    assert init == [0, 1, 0]
+    hand = R.myers_block_body(nw)
+    rng = np.random.default_rng(3)
+    st_a = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(2 * nw + 6)]
+    for w in range(nw):
+        st_a[2 * w + 1] &= ~st_a[2 * w]          # VP & VN == 0, the recurrence's invariant
+    planes = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(3 * nw)]
+    for cls in range(5):
+        a = [x.copy() for x in st_a]
+        b = [x.copy() for x in st_a]
+        auto.simulate(a, [], cls=cls, planes=planes)
+        hand.simulate(b, [], cls=cls, planes=planes)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_myers_two_groups_per_wave(oracle):
     q, s = _inputs(oracle, 77, 2, 32, 150, 150)
     nw = 5
