@@ -134,6 +134,18 @@ size_t bgsa_hip_group_words(int algo, int word_num, int k)
     return static_cast<size_t>(BGSA_CHAR_NUM) * word_num * HIP_V_NUM;
 }
 
+int bgsa_hip_release_workspace(void)
+{
+    void **slots[] = {&g_ws.d_content, &g_ws.d_peq, &g_ws.d_results, &g_ws.d_scratch};
+    size_t *caps[] = {&g_ws.cap_content, &g_ws.cap_peq, &g_ws.cap_results, &g_ws.cap_scratch};
+    for (int i = 0; i < 4; i++) {
+        if (*slots[i]) BGSA_HIP_TRY(hipFree(*slots[i]));
+        *slots[i] = nullptr;
+        *caps[i] = 0;
+    }
+    return BGSA_HIP_OK;
+}
+
 // ---- device-resident layer ---------------------------------------------------------------------
 
 const char *bgsa_hip_last_error(void) { return g_last_error.c_str(); }

@@ -92,7 +92,10 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k);
 /* hip_read_t elements per group of HIP_V_NUM subjects = BGSA_CHAR_NUM * word_num * HIP_V_NUM. */
 size_t bgsa_hip_group_words(int algo, int word_num, int k);
 
-/* ---- BGSA backend surface (host buffers) --------------------------------------------------- */
+/* ---- BGSA backend surface (host buffers) ---------------------------------------------------
+ * These three share one grow-only device workspace inside the library: call them from one thread
+ * at a time (the reference's pipeline calls its seams from the main thread only, cal_cpu.c:363-401).
+ * bgsa_hip_release_workspace() frees that workspace. */
 
 /* ASCII rows -> Peq blocks, layout [group][char 0..4][word][lane 0..63]
  * (replaces cpu_handle_reads, reference original/BGSA_CPU/global.c:25-70; for BGSA_ALGO_BANDED
@@ -115,6 +118,8 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
 void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_t *align_results,
                          int ref_len, int ref_count, int read_len, int read_count, int ref_start,
                          int ref_end, int word_num, int chunk_read_num, hip_data_t *dvdh_bit_mem);
+
+int bgsa_hip_release_workspace(void);
 
 /* ---- device-resident layer ----------------------------------------------------------------- */
 

@@ -14,4 +14,13 @@ for c in 2 3 4 5; do
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $out/prof_cfg$c.log 2>&1
   echo "prof cfg$c rc=$?" | tee -a $out/summary.txt
 done
+# PMC passes for the headline config (separate runs, as MI355X_MICROARCH.md §HBM prescribes)
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_$ctr -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_$ctr.log 2>&1
+  echo "pmc $ctr rc=$?" | tee -a $out/summary.txt
+done
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_SQ -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_SQ.log 2>&1
+echo "pmc SQ rc=$?" | tee -a $out/summary.txt
+# issue-rate microbenchmarks behind DESIGN.md §4.1
+( cd scripts/ubench && ./valu_rate 8 2000 > ../../$out/ubench_valu_rate.txt 2>&1; ./body_rate 20000 > ../../$out/ubench_body_rate.txt 2>&1 )
 tail -c 300 $out/pytest_gpu.log
