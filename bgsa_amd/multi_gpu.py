@@ -57,6 +57,43 @@ def plan_shards(n_subjects: int, world: int, ratios=None) -> list[Shard]:
     return shards
 
 
+class RatioBalancer:
+    """Per-device work ratios re-estimated from the previous bucket's device times — the reference's
+    `-D` dynamic mode (adjust_device_ratio3, original/BGSA_KNC/global.c:120-168): device 0 is the
+    unit; device i's ratio is scaled by t0/ti, then smoothed by a weighted mean over the rounds so
+    far in which round r weighs r.  Feed the result to plan_shards(ratios=...)."""
+
+    def __init__(self, n_devices: int, ratios=None):
+        self.ratios = [1.0] * n_devices if ratios is None else [float(r) for r in ratios]
+        if len(self.ratios) != n_devices or min(self.ratios) <= 0:
+            raise ValueError("need one positive ratio per device")
+        self.history: list[list[float]] = []   # loop_device_ratio of the reference
+
+    def update(self, times) -> list[float]:
+        times = [float(x) for x in times]
+        if len(times) != len(self.ratios) or min(times) <= 0:
+            raise ValueError("need one positive time per device")
+        new = list(self.ratios)
+        new[0] = 1.0
+        for i in range(1, len(new)):
+            new[i] = self.ratios[i] * times[0] / times[i]
+        rnd = len(self.history) + 1                      # time_index of the reference
+        if rnd > 1:
+            total = float(rnd)
+            acc = [new[i] * rnd for i in range(len(new))]
+            # the reference's loop starts at its second stored round (global.c:145: i = 1): round 1,
+            # measured with the initial guess, does not enter the mean
+            for r in range(1, rnd - 1):
+                for i in range(1, len(new)):
+                    acc[i] += self.history[r][i] * (r + 1)
+                total += r + 1
+            for i in range(1, len(new)):
+                new[i] = acc[i] / total
+        self.history.append(list(new))
+        self.ratios = new
+        return new
+
+
 class ShardedAligner:
     def __init__(self, dist=None, device=None, score_fn=None, algo: int = 0, k: int = 0):
         """dist: the torch.distributed module with an initialised process group, or None for 1 rank."""

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from bgsa_amd.multi_gpu import ShardedAligner, plan_shards  # noqa: E402
+from bgsa_amd.multi_gpu import RatioBalancer, ShardedAligner, plan_shards  # noqa: E402
 
 
 def test_plan_shards_properties():
@@ -33,6 +33,23 @@ def test_plan_shards_properties():
     assert skew[0].count == 64 * 25 and skew[1].count == 64 * 75
     with pytest.raises(ValueError):
         plan_shards(10, 2, ratios=[1, 0])
+
+
+def test_ratio_balancer_follows_device_times():
+    # a device that takes twice as long gets half the work; repeated identical measurements converge
+    b = RatioBalancer(3)
+    r1 = b.update([1.0, 2.0, 0.5])
+    assert r1 == [1.0, 0.5, 2.0]
+    for _ in range(6):
+        # times measured with the new split: device i now needs ratio_i / speed_i
+        speeds = [1.0, 0.5, 2.0]
+        times = [b.ratios[i] / speeds[i] for i in range(3)]
+        b.update(times)
+    assert abs(b.ratios[1] - 0.5) < 1e-9 and abs(b.ratios[2] - 2.0) < 1e-9
+    shards = plan_shards(64 * 700, 3, ratios=b.ratios)
+    assert [s.count for s in shards] == [64 * 200, 64 * 100, 64 * 400]
+    with pytest.raises(ValueError):
+        b.update([1.0, 0.0, 1.0])
 
 
 def _free_port():
