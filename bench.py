@@ -111,9 +111,15 @@ def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> d
                                      want_scores=False, tmp_root="/dev/shm" if Path("/dev/shm").is_dir() else None)
             rep = O.parse_gcups(out)
             if rep.get("cal_seconds", 0) > 0:
-                return {"value": cells / rep["cal_seconds"] / 1e9, "unit": "GCUPS", "cores": threads, "kind": "reference",
+                base = {"value": cells / rep["cal_seconds"] / 1e9, "unit": "GCUPS", "cores": threads, "kind": "reference",
                         "impl": f"reference {variant}/aligner -N {threads} (cal GCUPS, its own timer)",
                         "total_gcups": rep.get("total_gcups"), "sample": sample, "wall_s": round(time.time() - t0, 2)}
+                if algo == B.ALGO_MYERS:
+                    # The reference's AVX2 Myers kernel is generator output that is not committed
+                    # upstream (no JVM here): our own 8x32 AVX2 port of align_sse, for the record.
+                    _, secs = O.myers_avx2_timed(q_rows, s_rows[: ns // 8 * 8], threads=threads)
+                    base["avx2_port_gcups"] = round(float(nq) * (ns // 8 * 8) * qlen * slen / secs / 1e9, 2)
+                return base
         except Exception as e:  # fall through to the port
             print(f"[bench] reference baseline failed ({e}); using the oracle port", file=sys.stderr)
     if algo == B.ALGO_MYERS:
