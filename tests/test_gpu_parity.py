@@ -208,6 +208,39 @@ def test_long_carry_chains(oracle, length):
             assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BANDED, k=k), oracle.banded64(q, s, k))
 
 
+@pytest.mark.parametrize("algo,k", [(B.ALGO_BITPAL, 0), (B.ALGO_BANDED, 8), (B.ALGO_BANDED, 31)])
+def test_mid_size_properties_bitpal_and_banded(oracle, algo, k):
+    """400 x 64k pairs: planted identical pairs take the extreme score, duplicated subjects agree in
+    any group / lane, shuffling subjects permutes columns, and a random sample equals the oracle."""
+    import torch
+    rng = np.random.default_rng(11 + algo + k)
+    nq, ns = 400, 64 * 1024
+    q = oracle.gen_reads(181, nq, 150)
+    s = oracle.gen_reads(182, ns, 150)
+    planted = rng.choice(ns, size=nq, replace=False)
+    s[planted] = q
+    near = rng.choice(np.setdiff1d(np.arange(ns), planted), size=2000, replace=False)
+    s[near] = oracle.mutate(q[rng.integers(0, nq, 2000)], rng.integers(0, 12, 2000), 5)   # pairs that survive the band
+    a = B.DeviceAligner(algo, k=k)
+    a.set_queries(q)
+    a.set_subjects(s)
+    scores = a.score()
+    diag = scores[torch.arange(nq, device="cuda:0"), torch.from_numpy(planted).cuda()]
+    assert bool((diag == (300 if algo == B.ALGO_BITPAL else 0)).all())
+    perm = rng.permutation(ns)
+    b = B.DeviceAligner(algo, k=k)
+    b.set_queries(q)
+    b.set_subjects(s[perm])
+    assert bool((b.score() == scores[:, torch.from_numpy(perm).cuda()]).all())
+    fn = (lambda x, y: oracle.bitpal(x, y)) if algo == B.ALGO_BITPAL else (lambda x, y: oracle.banded64(x, y, k))
+    cols = np.concatenate([near[:96], rng.integers(0, ns, 96)])
+    want = fn(q[:24], s[cols])
+    got = scores[:24][:, torch.from_numpy(cols).cuda()].cpu().numpy()
+    assert np.array_equal(got, want)
+    if algo == B.ALGO_BANDED:
+        assert (want != 127).any() and (want == 127).any()
+
+
 def test_fuzz_all_algorithms(oracle):
     """Random lengths / counts / thresholds / alphabets through every kernel family."""
     rng = np.random.default_rng(2026)
