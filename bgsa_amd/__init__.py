@@ -76,6 +76,8 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     L.bgsa_hip_memset.argtypes = [vp, i32, sz, vp]
     L.bgsa_hip_stream_synchronize.argtypes = [vp]
+    L.bgsa_hip_stream_create.argtypes = [ctypes.POINTER(vp)]
+    L.bgsa_hip_stream_destroy.argtypes = [vp]
     L.bgsa_hip_set_device.argtypes = [i32]
     # host-buffer BGSA surface
     L.hip_handle_reads.argtypes = [vp, vp, i32, i64, i64]

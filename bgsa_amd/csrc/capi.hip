@@ -198,6 +198,19 @@ int bgsa_hip_memset(void *dst, int value, size_t bytes, void *stream)
     BGSA_HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
     return BGSA_HIP_OK;
 }
+int bgsa_hip_stream_create(void **stream)
+{
+    if (!stream) return BGSA_HIP_EINVAL;
+    hipStream_t s;
+    BGSA_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_stream_destroy(void *stream)
+{
+    BGSA_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return BGSA_HIP_OK;
+}
 int bgsa_hip_stream_synchronize(void *stream)
 {
     BGSA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));

@@ -5,7 +5,8 @@
  * cal_cpu.c:121-476), written from scratch in C against the C ABI of include/bgsa_hip.h:
  *
  *   ./aligner -q <query file> -d <database file> -f <result file> [-N host threads]
- *             [-k threshold] [-a myers|banded|bitpal] [-g gpu]
+ *             [-k threshold] [-a myers|banded|bitpal] [-n gpus] [-g first gpu | g0,g1,...]
+ *             [-R ratio file]
  *
  *   * input files: one sequence per line, all of one length (what `convert -f/-q` produces);
  *   * queries are mapped A,C,G,T,N -> 0..4 (file.c:117-140); the database is cut into read
@@ -22,6 +23,14 @@
  * query block is one asynchronous launch; a writer thread drains finished score blocks to disk
  * from a ring of pinned buffers while the GPU works on the next block (the reference's
  * input/output pthreads, thread.c:35-171, reduced to the one that matters here).
+ *
+ * With -n > 1 every bucket is cut into one contiguous slice of subject groups per GPU (the KNC
+ * backend's dispatch by ratio, BGSA_KNC/global.c:374-431, -R gives the ratios), each GPU scores
+ * all queries against its slice, and a query block is written as device 0's [queries][reads]
+ * tile, then device 1's, ... with the per-device counts recorded in `.info`
+ * (BGSA_KNC/cal_mic.c:475-476,535-536).  One host thread drives all GPUs: launches and copies are
+ * asynchronous, and each GPU alternates between two streams so that the copy-out of block i
+ * overlaps the kernel of block i+1.
  */
 #define _GNU_SOURCE
 #include <getopt.h>
@@ -37,7 +46,8 @@
 
 #define READ_BUCKET_SIZE 114857600LL /* original/BGSA_CPU/config.h:6 */
 #define REF_BUCKET_COUNT 100         /* original/BGSA_CPU/config.h:13 */
-#define RING 3
+#define RING 4
+#define MAX_DEV 16
 
 static double now(void)
 {
@@ -77,7 +87,7 @@ static int64_t file_size(const char *name)
 typedef struct {
     void *host[RING];
     size_t bytes[RING];
-    int state[RING]; /* 0 free, 1 filled */
+    int state[RING]; /* 0 free, 1 filled, 2 handed out and being filled */
     int head, tail, done;
     FILE *fp;
     double seconds;
@@ -90,8 +100,8 @@ static void *writer_main(void *arg)
     ring_t *r = (ring_t *)arg;
     for (;;) {
         pthread_mutex_lock(&r->lock);
-        while (!r->state[r->tail] && !r->done) pthread_cond_wait(&r->cond, &r->lock);
-        if (!r->state[r->tail] && r->done) {
+        while (r->state[r->tail] != 1 && !r->done) pthread_cond_wait(&r->cond, &r->lock);
+        if (r->state[r->tail] != 1) {
             pthread_mutex_unlock(&r->lock);
             return NULL;
         }
@@ -116,6 +126,8 @@ static int ring_acquire(ring_t *r)
     pthread_mutex_lock(&r->lock);
     while (r->state[r->head]) pthread_cond_wait(&r->cond, &r->lock);
     int slot = r->head;
+    r->state[slot] = 2;
+    r->head = (slot + 1) % RING;
     pthread_mutex_unlock(&r->lock);
     return slot;
 }
@@ -125,7 +137,6 @@ static void ring_publish(ring_t *r, int slot, size_t bytes)
     pthread_mutex_lock(&r->lock);
     r->bytes[slot] = bytes;
     r->state[slot] = 1;
-    r->head = (slot + 1) % RING;
     pthread_cond_broadcast(&r->cond);
     pthread_mutex_unlock(&r->lock);
 }
@@ -139,39 +150,144 @@ static void usage(void)
     printf("  -N <arg>\n\t Number of host threads. \n\n");
     printf("  -k <arg>\n\t Filter threshold (banded). \n\n");
     printf("  -a <arg>\n\t Algorithm: myers (default), banded, bitpal. \n\n");
-    printf("  -g <arg>\n\t GPU index. Default 0. \n\n");
+    printf("  -n <arg>\n\t Number of GPUs. Default 1. \n\n");
+    printf("  -g <arg>\n\t First GPU index, or a comma separated list of GPU indices. Default 0. \n\n");
+    printf("  -R <arg>\n\t File with one work ratio per GPU (one number per line). Default: equal. \n\n");
     exit(1);
+}
+
+/* ---- input thread: reads the next bucket while the GPUs score the current one (thread.c:35-113) */
+typedef struct {
+    FILE *fp;
+    char *rows;
+    int64_t want, row, count;
+    int read_len, extra;
+    double seconds;
+} read_job_t;
+
+static void *read_bucket(void *arg)
+{
+    read_job_t *j = (read_job_t *)arg;
+    const double t0 = now();
+    size_t n = fread(j->rows, 1, (size_t)(j->want * j->row), j->fp);
+    if ((int64_t)n < j->want * j->row) j->rows[n++] = '\n'; /* file without a final newline */
+    j->count = j->want;
+    j->extra = 0;
+    while (j->count % HIP_V_NUM) { /* pad the last bucket with all-'N' reads (file.c:84-112) */
+        memset(j->rows + j->count * j->row, 'N', (size_t)j->read_len);
+        j->rows[j->count * j->row + j->read_len] = '\n';
+        j->count++;
+        j->extra++;
+    }
+    j->seconds += now() - t0;
+    return NULL;
+}
+
+/* One GPU's share of the pipeline. */
+typedef struct {
+    int gpu;
+    double ratio;
+    void *d_rows, *d_peq, *d_q;
+    void *stream[2], *d_out[2], *d_work[2];
+    int64_t first, count;      /* slice of the current bucket, in reads */
+} device_t;
+
+/* Cut `groups` subject groups into one contiguous run per device, proportional to the ratios.
+ * The last device always gets a group: the padding reads at the end of a bucket are recorded in
+ * `.info` as belonging to it (convert.c drops `extra_count` scores from the last device's tile
+ * only, BGSA_KNC/convert.c:246-254).  What rounding leaves over goes round-robin from device 0. */
+static void plan_slices(device_t *dev, int n, int64_t groups)
+{
+    double total = 0;
+    for (int d = 0; d < n; d++) total += dev[d].ratio;
+    int64_t given = 0;
+    for (int d = 0; d < n; d++) {
+        dev[d].count = (int64_t)((double)groups * dev[d].ratio / total);
+        given += dev[d].count;
+    }
+    if (groups > 0 && dev[n - 1].count == 0) {
+        dev[n - 1].count = 1;
+        if (given < groups) {
+            given++;
+        } else { /* nothing left over: the widest slice gives one up */
+            int widest = 0;
+            for (int d = 1; d < n - 1; d++) if (dev[d].count > dev[widest].count) widest = d;
+            dev[widest].count--;
+        }
+    }
+    for (int d = 0; given < groups; d = (d + 1) % n) { dev[d].count++; given++; }
+    int64_t first = 0;
+    for (int d = 0; d < n; d++) {
+        dev[d].count *= HIP_V_NUM;
+        dev[d].first = first;
+        first += dev[d].count;
+    }
 }
 
 int main(int argc, char **argv)
 {
     const char *file_query = NULL, *file_database = NULL, *file_result = "result.txt";
-    int algo = BGSA_ALGO_MYERS, gpu = 0, c;
+    const char *gpu_list = "0", *file_ratio = NULL;
+    int algo = BGSA_ALGO_MYERS, n_dev = 1, c;
     threshold = HIP_BANDED_WORD_SIZE / 2 - 1; /* banded/BGSA_CPU/main.c:43 */
-    while ((c = getopt(argc, argv, "t:q:d:f:n:N:k:a:g:R:Dh")) != -1) {
+    while ((c = getopt(argc, argv, "t:q:d:f:n:N:M:k:a:g:R:Dh")) != -1) {
         switch (c) {
         case 'q': file_query = optarg; break;
         case 'd': file_database = optarg; break;
         case 'f': file_result = optarg; break;
         case 'N': cpu_threads = atoi(optarg); break;
         case 'k': threshold = atoi(optarg); break;
-        case 'g': gpu = atoi(optarg); break;
+        case 'g': gpu_list = optarg; break;
+        case 'n': n_dev = atoi(optarg); break;
+        case 'R': file_ratio = optarg; break;
         case 'a':
             if (!strcmp(optarg, "myers")) algo = BGSA_ALGO_MYERS;
             else if (!strcmp(optarg, "banded")) algo = BGSA_ALGO_BANDED;
             else if (!strcmp(optarg, "bitpal")) algo = BGSA_ALGO_BITPAL;
             else usage();
             break;
-        case 't': case 'n': case 'R': case 'D': break; /* KNC-only knobs: accepted, ignored */
+        case 't': case 'M': case 'D': break; /* KNC-only knobs: accepted, ignored */
         default: usage();
         }
     }
     if (!file_query) { printf("Query file can't be empty.\n"); exit(1); }
     if (!file_database) { printf("Database file can't be empty. \n"); exit(1); }
+    if (n_dev < 1 || n_dev > MAX_DEV) { printf("Error - the number of GPUs must be 1..%d\n", MAX_DEV); exit(1); }
 
-    double total_start = now(), read_time = 0, mem_time = 0, cal_time = 0;
+    /* ---- which GPUs, and their work ratios ------------------------------------------------------ */
+    device_t dev[MAX_DEV];
+    memset(dev, 0, sizeof dev);
+    {
+        int listed = 0;
+        const char *s = gpu_list;
+        while (*s && listed < MAX_DEV) {
+            dev[listed++].gpu = atoi(s);
+            while (*s && *s != ',') s++;
+            if (*s == ',') s++;
+        }
+        if (listed > 1) n_dev = listed;                                   /* an explicit list wins */
+        else for (int d = 1; d < n_dev; d++) dev[d].gpu = dev[0].gpu + d; /* -g first, -n count */
+        const int present = bgsa_hip_device_count();
+        for (int d = 0; d < n_dev; d++) {
+            if (dev[d].gpu < 0 || dev[d].gpu >= present) {
+                printf("Error - GPU %d does not exist (%d visible)\n", dev[d].gpu, present);
+                exit(1);
+            }
+            dev[d].ratio = 1.0;
+        }
+        if (file_ratio) {
+            FILE *fr = open_or_die(file_ratio, "r");
+            for (int d = 0; d < n_dev; d++)
+                if (fscanf(fr, "%lf", &dev[d].ratio) != 1 || dev[d].ratio <= 0) {
+                    printf("Error - %s needs one positive ratio per GPU\n", file_ratio);
+                    exit(1);
+                }
+            fclose(fr);
+        }
+    }
+
+    double total_start = now(), mem_time = 0, cal_time = 0;
     CK(bgsa_hip_select_algorithm(algo));
-    CK(bgsa_hip_set_device(gpu));
     init_mapping_table();
     const size_t esz = algo == BGSA_ALGO_BANDED ? sizeof(hip_banded_write_t) : sizeof(hip_write_t);
 
@@ -210,18 +326,27 @@ int main(int argc, char **argv)
     const int word_num = bgsa_hip_word_num(algo, ref_len, read_len, threshold);
     const int64_t max_reads = total_reads < per_bucket ? (total_reads + HIP_V_NUM - 1) / HIP_V_NUM * HIP_V_NUM : per_bucket;
     const size_t rows_bytes = (size_t)(max_reads * row);
-    const size_t peq_bytes = bgsa_hip_group_words(algo, word_num, threshold) * sizeof(hip_read_t) * (size_t)(max_reads / HIP_V_NUM);
     const size_t block_bytes = (size_t)REF_BUCKET_COUNT * (size_t)max_reads * esz;
     const size_t work_bytes = bgsa_hip_workspace_bytes(algo, ref_len, read_len, REF_BUCKET_COUNT);
 
-    void *h_rows, *d_rows, *d_peq, *d_q, *d_out, *d_work;
+    /* the widest slice any device can be handed: sizes every per-device allocation once */
+    plan_slices(dev, n_dev, max_reads / HIP_V_NUM);
+    void *h_rows;
     CK(bgsa_hip_malloc_host(&h_rows, rows_bytes));
-    CK(bgsa_hip_malloc(&d_rows, rows_bytes));
-    CK(bgsa_hip_malloc(&d_peq, peq_bytes));
-    CK(bgsa_hip_malloc(&d_q, (size_t)qsize + 8));
-    CK(bgsa_hip_malloc(&d_out, block_bytes));
-    CK(bgsa_hip_malloc(&d_work, work_bytes));
-    CK(bgsa_hip_memcpy_h2d(d_q, qbuf, (size_t)qsize, NULL));
+    for (int d = 0; d < n_dev; d++) {
+        device_t *v = &dev[d];
+        const int64_t cap = v->count + 2 * HIP_V_NUM; /* rounding moves at most two groups between buckets */
+        CK(bgsa_hip_set_device(v->gpu));
+        CK(bgsa_hip_malloc(&v->d_rows, (size_t)(cap * row)));
+        CK(bgsa_hip_malloc(&v->d_peq, bgsa_hip_group_words(algo, word_num, threshold) * sizeof(hip_read_t) * (size_t)(cap / HIP_V_NUM)));
+        CK(bgsa_hip_malloc(&v->d_q, (size_t)qsize + 8));
+        CK(bgsa_hip_memcpy_h2d(v->d_q, qbuf, (size_t)qsize, NULL));
+        for (int s = 0; s < 2; s++) {
+            CK(bgsa_hip_stream_create(&v->stream[s]));
+            CK(bgsa_hip_malloc(&v->d_out[s], (size_t)REF_BUCKET_COUNT * (size_t)cap * esz));
+            CK(bgsa_hip_malloc(&v->d_work[s], work_bytes ? work_bytes : 8));
+        }
+    }
 
     ring_t ring;
     memset(&ring, 0, sizeof ring);
@@ -232,59 +357,98 @@ int main(int argc, char **argv)
     char *info_name = (char *)malloc(strlen(file_result) + 6);
     sprintf(info_name, "%s.info", file_result);
     FILE *finfo = open_or_die(info_name, "wb+");
-    const int device_num = 1;
     fwrite(&bucket_num, sizeof(int), 1, finfo);
-    fwrite(&device_num, sizeof(int), 1, finfo);
+    fwrite(&n_dev, sizeof(int), 1, finfo);
     fwrite(&ref_count, sizeof(int64_t), 1, finfo);
     pthread_t writer;
     pthread_create(&writer, NULL, writer_main, &ring);
 
     int64_t subjects_done = 0;
+    read_job_t job = {fd, (char *)h_rows, 0, row, 0, read_len, 0, 0.0};
+    pthread_t reader;
+    int reading = 0;
     for (int b = 0; b < bucket_num; b++) {
-        /* ---- read one bucket of rows, pad the last one with 'N' reads ---------------------- */
-        double t0 = now();
-        int64_t want = total_reads - (int64_t)b * per_bucket;
-        if (want > per_bucket) want = per_bucket;
-        size_t n = fread(h_rows, 1, (size_t)(want * row), fd);
-        char *rows = (char *)h_rows;
-        if ((int64_t)n < want * row) rows[n++] = '\n'; /* file without a final newline */
-        int64_t count = want;
-        int extra = 0;
-        while (count % HIP_V_NUM) {
-            memset(rows + count * row, 'N', (size_t)read_len);
-            rows[count * row + read_len] = '\n';
-            count++;
-            extra++;
+        /* ---- the bucket the input thread read while the previous one was being scored -------- */
+        if (reading) {
+            pthread_join(reader, NULL);
+            reading = 0;
+        } else {
+            job.want = total_reads < per_bucket ? total_reads : per_bucket;
+            read_bucket(&job);
         }
-        read_time += now() - t0;
-        fwrite(&count, sizeof(int64_t), 1, finfo);
+        double t0;
+        char *rows = job.rows;
+        const int64_t count = job.count;
+        const int extra = job.extra;
+        plan_slices(dev, n_dev, count / HIP_V_NUM);
+        for (int d = 0; d < n_dev; d++) fwrite(&dev[d].count, sizeof(int64_t), 1, finfo);
         fwrite(&extra, sizeof(int), 1, finfo);
         fflush(finfo);
 
-        /* ---- upload + preprocess on the GPU ("mem" time of the reference report) ------------ */
+        /* ---- upload + preprocess on the GPUs ("mem" time of the reference report) ----------- */
         t0 = now();
-        CK(bgsa_hip_memcpy_h2d(d_rows, rows, (size_t)(count * row), NULL));
-        CK(bgsa_hip_handle_reads_dev(algo, (const char *)d_rows, count * row, read_len, count, word_num,
-                                     threshold, (hip_read_t *)d_peq, NULL));
-        CK(bgsa_hip_stream_synchronize(NULL));
+        for (int d = 0; d < n_dev; d++) {
+            device_t *v = &dev[d];
+            if (!v->count) continue;
+            CK(bgsa_hip_set_device(v->gpu));
+            CK(bgsa_hip_memcpy_h2d(v->d_rows, rows + v->first * row, (size_t)(v->count * row), v->stream[0]));
+            CK(bgsa_hip_handle_reads_dev(algo, (const char *)v->d_rows, v->count * row, read_len, v->count, word_num,
+                                         threshold, (hip_read_t *)v->d_peq, v->stream[0]));
+        }
+        for (int d = 0; d < n_dev; d++) {
+            CK(bgsa_hip_set_device(dev[d].gpu));
+            CK(bgsa_hip_stream_synchronize(dev[d].stream[0]));
+        }
         mem_time += now() - t0;
+        if (b + 1 < bucket_num) { /* the rows are in HBM now: the host buffer is free for the next bucket */
+            job.want = total_reads - (int64_t)(b + 1) * per_bucket;
+            if (job.want > per_bucket) job.want = per_bucket;
+            pthread_create(&reader, NULL, read_bucket, &job);
+            reading = 1;
+        }
 
-        /* ---- query blocks of REF_BUCKET_COUNT (cal_cpu.c:363-401) --------------------------------- */
-        for (int64_t ref_start = 0; ref_start < ref_count; ref_start += REF_BUCKET_COUNT) {
+        /* ---- query blocks of REF_BUCKET_COUNT (cal_cpu.c:363-401), two in flight per GPU ------ */
+        t0 = now();
+        double stalled = 0;
+        int slot_of[2] = {-1, -1};
+        size_t bytes_of[2] = {0, 0};
+        int64_t issued = 0;
+        for (int64_t ref_start = 0;; ref_start += REF_BUCKET_COUNT, issued++) {
+            const int s = (int)(issued & 1);
+            if (slot_of[s] >= 0) { /* the block issued two steps ago on this stream pair: finish and hand over */
+                for (int d = 0; d < n_dev; d++) {
+                    CK(bgsa_hip_set_device(dev[d].gpu));
+                    CK(bgsa_hip_stream_synchronize(dev[d].stream[s]));
+                }
+                ring_publish(&ring, slot_of[s], bytes_of[s]);
+                slot_of[s] = -1;
+            }
+            if (ref_start >= ref_count) {
+                if (slot_of[s ^ 1] < 0) break;
+                continue; /* one more turn drains the other stream pair */
+            }
             int64_t ref_end = ref_start + REF_BUCKET_COUNT;
             if (ref_end > ref_count) ref_end = ref_count;
-            const size_t bytes = (size_t)(ref_end - ref_start) * (size_t)count * esz;
-            t0 = now();
-            CK(bgsa_hip_cal_align_score_dev(algo, (const char *)d_q, (const hip_read_t *)d_peq, d_out, ref_len,
-                                            read_len, count, (int)ref_start, (int)ref_end, word_num, threshold,
-                                            d_work, work_bytes, NULL));
-            CK(bgsa_hip_stream_synchronize(NULL));
-            cal_time += now() - t0;
-            int slot = ring_acquire(&ring);
-            CK(bgsa_hip_memcpy_d2h(ring.host[slot], d_out, bytes, NULL));
-            CK(bgsa_hip_stream_synchronize(NULL));
-            ring_publish(&ring, slot, bytes);
+            const int64_t nq = ref_end - ref_start;
+            double w0 = now();
+            const int slot = ring_acquire(&ring);
+            if (slot_of[s ^ 1] < 0) stalled += now() - w0; /* nothing in flight: the GPUs sat idle */
+            char *dst = (char *)ring.host[slot];
+            for (int d = 0; d < n_dev; d++) {
+                device_t *v = &dev[d];
+                if (!v->count) continue;
+                CK(bgsa_hip_set_device(v->gpu));
+                CK(bgsa_hip_cal_align_score_dev(algo, (const char *)v->d_q, (const hip_read_t *)v->d_peq, v->d_out[s],
+                                                ref_len, read_len, v->count, (int)ref_start, (int)ref_end, word_num,
+                                                threshold, v->d_work[s], work_bytes, v->stream[s]));
+                /* device tiles one after another inside the block (cal_mic.c:535-536) */
+                CK(bgsa_hip_memcpy_d2h(dst + (size_t)nq * (size_t)v->first * esz, v->d_out[s],
+                                       (size_t)nq * (size_t)v->count * esz, v->stream[s]));
+            }
+            slot_of[s] = slot;
+            bytes_of[s] = (size_t)nq * (size_t)count * esz;
         }
+        cal_time += now() - t0 - stalled; /* time with scoring work in flight on the GPUs */
         subjects_done += count;
     }
     pthread_mutex_lock(&ring.lock);
@@ -299,13 +463,14 @@ int main(int argc, char **argv)
 
     /* ---- the reference's report (cal_cpu.c:459-475) ---------------------------------------- */
     printf("score is %d, %d, %d\n", match_score, mismatch_score, gap_score);
-    printf("read_total_time  is %.2fs\n", read_time);
+    printf("read_total_time  is %.2fs\n", job.seconds);
     printf("write_total_time is %.2fs\n", ring.seconds);
     printf("mem_total_time is   %.2fs\n\n", mem_time);
     printf("query_len    is %d\n", ref_len);
     printf("query_count  is %ld\n", (long)ref_count);
     printf("subject_len   is %d\n", read_len);
     printf("subject_count is %ld\n\n", (long)subjects_done);
+    printf("gpu_count     is %d\n", n_dev);
     printf("cal_total_times     is %.2fs\n", cal_time);
     printf("total time          is %.2fs\n", total);
     const double cells = 1.0 * ref_len * ref_count * read_len * subjects_done;
@@ -314,7 +479,15 @@ int main(int argc, char **argv)
 
     for (int i = 0; i < RING; i++) bgsa_hip_free_host(ring.host[i]);
     bgsa_hip_free_host(h_rows);
-    bgsa_hip_free(d_rows); bgsa_hip_free(d_peq); bgsa_hip_free(d_q); bgsa_hip_free(d_out); bgsa_hip_free(d_work);
+    for (int d = 0; d < n_dev; d++) {
+        device_t *v = &dev[d];
+        bgsa_hip_set_device(v->gpu);
+        bgsa_hip_free(v->d_rows); bgsa_hip_free(v->d_peq); bgsa_hip_free(v->d_q);
+        for (int s = 0; s < 2; s++) {
+            bgsa_hip_stream_destroy(v->stream[s]);
+            bgsa_hip_free(v->d_out[s]); bgsa_hip_free(v->d_work[s]);
+        }
+    }
     free_mem(qbuf);
     free(info_name);
     return 0;

@@ -141,6 +141,8 @@ int bgsa_hip_free_host(void *hptr);
 int bgsa_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int bgsa_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int bgsa_hip_memset(void *dst, int value, size_t bytes, void *stream);
+int bgsa_hip_stream_create(void **stream);   /* on the current device */
+int bgsa_hip_stream_destroy(void *stream);
 int bgsa_hip_stream_synchronize(void *stream);
 
 /* Subject preprocess ON the GPU: d_rows = read_count rows of (len+1) ASCII bytes in device

@@ -17,13 +17,14 @@ ROOT = HOST.parent.parent
 ALGO_FLAG = {"original_cpu": "myers", "original_avx2": "bitpal", "banded_cpu": "banded"}
 
 
-def _run_cli(tmp_path, g, bucket_bytes=None, converter=None):
+def _run_cli(tmp_path, g, bucket_bytes=None, converter=None, extra_args=()):
     (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
     (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
     cmd = [str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-f", "result.txt",
            "-a", ALGO_FLAG[g["variant"]]]
     if g["k"] >= 0:
         cmd += ["-k", str(g["k"])]
+    cmd += list(extra_args)
     env = dict(os.environ)
     if bucket_bytes:
         env["BGSA_READ_BUCKET_SIZE"] = str(bucket_bytes)
@@ -64,3 +65,62 @@ def test_reference_convert_reads_our_result_files(tmp_path):
     g = load_golden("f1_myers_150")
     got, _ = _run_cli(tmp_path, g, bucket_bytes=128 * 151, converter=ref_convert)
     assert np.array_equal(got, g["scores"])
+
+
+# ---- several GPUs from one process (-n / -g list / -R): this box has one card, so the same card is
+# listed more than once — every listed entry gets its own slice, buffers and streams, which is the
+# whole multi-device code path ------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["f1_myers_150", "f7_bitpal_150", "f8_banded_k8_150"])
+def test_cli_two_devices_matches_golden(tmp_path, name):
+    g = load_golden(name)
+    got, report = _run_cli(tmp_path, g, extra_args=["-g", "0,0"])
+    assert np.array_equal(got, g["scores"])
+    assert "gpu_count     is 2" in report
+    info = (tmp_path / "result.txt.info").read_bytes()
+    assert np.frombuffer(info[4:8], dtype=np.int32)[0] == 2
+
+
+def test_cli_three_devices_ratios_buckets_and_blocks(tmp_path, oracle):
+    # 3 devices with ratios 1 : 2.5 : 0.5, 3 read buckets (the last padded), 3 query blocks
+    q = oracle.gen_reads(93, 230, 150)
+    s = oracle.gen_reads(94, 1000, 150)
+    (tmp_path / "ratio.txt").write_text("1\n2.5\n0.5\n")
+    g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
+    got, report = _run_cli(tmp_path, g, bucket_bytes=384 * 151 + 10, extra_args=["-g", "0,0,0", "-R", "ratio.txt"])
+    assert np.array_equal(got, oracle.myers64(q, s))
+    info = (tmp_path / "result.txt.info").read_bytes()
+    n_buckets, n_dev = np.frombuffer(info[:8], dtype=np.int32)
+    assert (n_buckets, n_dev) == (3, 3)
+    rec = 8 * 3 + 4
+    counts = [np.frombuffer(info[16 + b * rec: 16 + b * rec + 24], dtype=np.int64) for b in range(3)]
+    assert [int(c.sum()) for c in counts] == [384, 384, 256]            # 232 reads + 24 padding reads
+    assert all(int(x) % 64 == 0 for c in counts for x in c)
+    assert counts[0][1] > counts[0][0] > counts[0][2]                    # follows the ratios
+    assert np.frombuffer(info[16 + 2 * rec + 24: 16 + 3 * rec], dtype=np.int32)[0] == 24
+
+
+def test_cli_more_devices_than_groups(tmp_path, oracle):
+    # 100 subjects = 2 groups on 3 devices: one device gets nothing and the files still decode
+    q = oracle.gen_reads(95, 7, 150)
+    s = oracle.gen_reads(96, 100, 150)
+    g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
+    got, _ = _run_cli(tmp_path, g, extra_args=["-g", "0,0,0"])
+    assert np.array_equal(got, oracle.myers64(q, s))
+
+
+def test_reference_knc_convert_reads_multi_device_result(tmp_path):
+    ref_convert = ROOT / "oracle" / "_ref" / "original_knc" / "convert"
+    if not ref_convert.exists():
+        pytest.skip("reference KNC converter not built (oracle/_ref)")
+    g = load_golden("f6_myers_ns100")
+    got, _ = _run_cli(tmp_path, g, converter=ref_convert, extra_args=["-n", "2", "-g", "0,0"])
+    assert np.array_equal(got, g["scores"])
+
+
+def test_cli_rejects_missing_gpu(tmp_path):
+    g = load_golden("f1_myers_150")
+    (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
+    (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
+    p = subprocess.run([str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-g", "63"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert p.returncode != 0 and "does not exist" in p.stdout
