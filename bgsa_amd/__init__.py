@@ -53,10 +53,17 @@ def lib() -> ctypes.CDLL:
         raise BgsaHipError(
             f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C bgsa_amd/csrc`.  There is no CPU fallback for the HIP path.")
+    # torch first: it bundles its own ROCm runtime, and the process must end up with ONE HIP/HSA
+    # runtime.  Loaded in the other order (this library pulling in /opt/rocm's libamdhip64 before torch
+    # brings its libhsa-runtime64) the runtime finds no device.
+    import torch  # noqa: F401
     L = ctypes.CDLL(str(LIB_PATH))
     vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
     L.bgsa_hip_last_error.restype = ctypes.c_char_p
     L.bgsa_hip_select_algorithm.argtypes = [i32]
+    L.bgsa_hip_select_scores.argtypes = [i32, i32, i32]
+    ip = ctypes.POINTER(i32)
+    L.bgsa_hip_score_set.argtypes = [i32, ip, ip, ip, ip]
     L.bgsa_hip_word_num.argtypes = [i32, i32, i32, i32]
     L.bgsa_hip_group_words.argtypes = [i32, i32, i32]
     L.bgsa_hip_group_words.restype = sz
@@ -107,6 +114,16 @@ class SeqT(ctypes.Structure):
                 ("content", ctypes.c_void_p)]
 
 
+def score_sets() -> list[tuple[int, int, int]]:
+    """The (match, mismatch, gap) sets BitPAl kernels were compiled for (Makefile BITPAL_SETS)."""
+    out = []
+    for i in range(lib().bgsa_hip_score_set_count()):
+        m, x, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().bgsa_hip_score_set(i, ctypes.byref(m), ctypes.byref(x), ctypes.byref(g), None), "score_set")
+        out.append((m.value, x.value, g.value))
+    return out
+
+
 def word_num(algo: int, qlen: int, slen: int, k: int = 0) -> int:
     return int(lib().bgsa_hip_word_num(algo, qlen, slen, k))
 
@@ -146,10 +163,14 @@ class DeviceAligner:
     252-401): preprocess the bucket once, then loop over query buckets calling the grid.
     """
 
-    def __init__(self, algo: int = ALGO_MYERS, device: str = "cuda:0", k: int = 0):
+    def __init__(self, algo: int = ALGO_MYERS, device: str = "cuda:0", k: int = 0, scores=None):
+        """scores: (match, mismatch, gap) for ALGO_BITPAL; None = the reference's 2 / -3 / -5."""
         import torch
         self.torch = torch
         self.algo, self.k = algo, int(k)
+        self.scores = tuple(int(x) for x in scores) if scores is not None else None
+        if self.scores is not None and algo != ALGO_BITPAL:
+            raise BgsaHipError("scores only apply to ALGO_BITPAL")
         self.device = torch.device(device)
         if not torch.cuda.is_available():
             raise BgsaHipError("no GPU visible: the HIP path has no CPU fallback")
@@ -199,6 +220,7 @@ class DeviceAligner:
         ref_end = self.nq if ref_end is None else ref_end
         if out is None:
             out = torch.empty((ref_end - ref_start, self.ns), dtype=self.out_dtype, device=self.device)
+        self._select()
         need = int(lib().bgsa_hip_workspace_bytes(self.algo, self.qlen, self.slen, ref_end - ref_start))
         if getattr(self, "d_work", None) is None or self.d_work.numel() < need:
             self.d_work = torch.empty(max(need, 8), dtype=torch.uint8, device=self.device)
@@ -208,14 +230,20 @@ class DeviceAligner:
                                                  self.d_work.numel(), self._stream()), "cal_align_score_dev")
         return out
 
+    def _select(self) -> None:
+        # the score set is process-global state of the C ABI (the reference's three ints)
+        if self.algo == ALGO_BITPAL:
+            check(lib().bgsa_hip_select_scores(*(self.scores or (2, -3, -5))), "select_scores")
+
     def kernel_name(self) -> str:
+        self._select()
         return lib().bgsa_hip_kernel_name(self.algo, self.wn).decode()
 
 
 def align_all_pairs(queries: np.ndarray, subjects: np.ndarray, algo: int = ALGO_MYERS, k: int = 0,
-                    device: str = "cuda:0") -> np.ndarray:
+                    device: str = "cuda:0", scores=None) -> np.ndarray:
     """Convenience: scores[nq, ns] for small inputs, through the device-resident C ABI."""
-    a = DeviceAligner(algo, device, k)
+    a = DeviceAligner(algo, device, k, scores)
     a.set_queries(queries)
     a.set_subjects(subjects)
     out = a.score()

@@ -149,6 +149,24 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
                   void *d_workspace, hipStream_t stream);
 const char *banded_kernel_name(int word_num);
 
+// One compiled BitPAl score set (bitpal.hip; the kernels come from gen_bitpal_sets.py).
+struct BitpalSet {
+    int match, mismatch, gap;
+    int planes;      // bit-planes of state per 32 subject columns
+    int chains;      // inter-word carry chains per row (carry words per 32 rows of a column block)
+    int max_plain;   // widest subject, in words, whose state stays in registers; beyond: column blocks
+    int valu_per_word;
+    int (*launch)(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
+                  int64_t read_count, int ref_start, int ref_end, int word_num, void *d_workspace,
+                  hipStream_t stream);
+    const char *(*kernel_name)(int word_num);
+};
+int bitpal_set_count();
+const BitpalSet *bitpal_set_at(int i);
+const BitpalSet *bitpal_find_set(int match, int mismatch, int gap);  // nullptr: not compiled in
+const BitpalSet *bitpal_current_set();  // the set of the ABI's score globals; nullptr + error text if absent
+
+// Scores with the set selected by the ABI's match_score / mismatch_score / gap_score.
 int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                   void *d_workspace, hipStream_t stream);
@@ -157,7 +175,11 @@ const char *bitpal_kernel_name(int word_num);
 // long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.
 inline bool beyond_registers(int algo, int word_num)
 {
-    return (algo == BGSA_ALGO_MYERS && word_num > kMaxWords) || (algo == BGSA_ALGO_BITPAL && word_num > 8);
+    if (algo == BGSA_ALGO_BITPAL) {
+        const BitpalSet *s = bitpal_current_set();
+        return s && word_num > s->max_plain;
+    }
+    return algo == BGSA_ALGO_MYERS && word_num > kMaxWords;
 }
 // Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.
 constexpr int kBlockedBlocks = 512;  // persistent workgroups of myers_blocked_kernel

@@ -1,0 +1,229 @@
+// bitpal_kernels.inl — the BitPAl kernels and launchers of ONE score set.  Included by a generated
+// translation unit (_gen/bitpal_set_<tag>.hip, gen_bitpal_sets.py) inside `namespace bgsa::<set>`,
+// right after that set's generated row loops (bitpal_rows_gen.inc for the default 2/-3/-5, or
+// _gen/bitpal_rows_<tag>.inc), which define kBitpalPlanes, kBitpalChains, kBitpalGap, kBitpalWeights,
+// the width lists and bitpal_rows_asm<NW> / bitpal_block_rows_asm<NW>.
+//
+// Replaces the reference's align_avx hot loop (original/BGSA_AVX2/align_core.c:164-482 for the
+// committed 2/-3/-5 instance; generator/.../BitPAlGenerator.java:151-534 for any other scores).
+// Same decomposition as myers_global.hip: lane = subject, wave = group of 64, the wave keeps its
+// Peq block in VGPRs and walks a tile of queries; the row loop is generated threaded-code asm
+// (rows_ir.py: bitpal_body), every inter-word carry a VCC add-with-carry chain on full 32-bit words.
+//
+// Final score (align_core.c:433-471 generalised): gap*(qlen + slen) + sum over subject columns of
+// (dH - gap), i.e. one masked popcount per plane and word, weighted by kBitpalWeights.
+
+template <int NW>
+__device__ __forceinline__ int bitpal_column_sum(const uint32_t *st, int first_word, int read_len)
+{
+    int sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int rem = read_len - 32 * (first_word + w);
+        const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+#pragma unroll
+        for (int i = 0; i < kBitpalPlanes; i++) sum += kBitpalWeights[i] * __popc(st[w * kBitpalPlanes + i] & m);
+    }
+    return sum;
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void bitpal_asm_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
+    int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (group >= n_groups) return;
+
+    uint32_t P[kChars][NW];
+    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+#pragma unroll
+    for (int c = 0; c < kChars; c++)
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            P[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        uint32_t st[kBitpalPlanes * NW];
+#pragma unroll
+        for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = 0u;  // every column starts at dH = gap (:167-171)
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        bitpal_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        const int score = kBitpalGap * (ref_len + read_len) + bitpal_column_sum<NW>(st, 0, read_len);
+        dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(score);
+    }
+}
+
+// Subjects wider than kBitpalMaxPlain words: column blocks of NW words, the carry chains of a row
+// crossing block boundaries through per-wave carry words (same scheme as myers_blocked_kernel;
+// rows_ir.py: make_blocked, CPU-simulated in tests/test_rows_ir.py).
+template <int NW>
+__global__ __launch_bounds__(256) void bitpal_blocked_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
+    uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks)
+{
+    constexpr int NC = kBitpalChains;
+    constexpr int NS = kBitpalPlanes * NW;
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int wave = threadIdx.x >> 6;
+    const int n_chunks = (ref_len + 31) / 32;
+    uint32_t *carry = carry_all + (static_cast<size_t>(blockIdx.x) * kWavesPerBlock + wave) * n_chunks * NC * kLanes;
+    const unsigned long long carry_base = uniform_u64(reinterpret_cast<unsigned long long>(carry));
+    const int q_tiles = (n_queries + q_tile - 1) / q_tile;
+    const long long n_tasks = static_cast<long long>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock) * q_tiles;
+    const int tail_rows = ref_len & 31;
+
+    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int group = __builtin_amdgcn_readfirstlane(static_cast<int>(task / q_tiles) * kWavesPerBlock + wave);
+        const int tile = static_cast<int>(task % q_tiles);
+        if (group >= n_groups) continue;  // wave-uniform
+        const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+        const int q0 = tile * q_tile;
+        const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+        for (int q = q0; q < q1; q++) {
+            for (int i = 0; i < n_chunks * NC; i++) carry[i * kLanes + lane] = 0u;  // every chain starts at carry-in 0
+            const unsigned long long s =
+                reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+            int score = kBitpalGap * (ref_len + read_len);
+            for (int blk = 0; blk < n_blocks; blk++) {
+                uint32_t P[kChars][NW];
+#pragma unroll
+                for (int c = 0; c < kChars; c++)
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const int gw = blk * NW + w;
+                        P[c][w] = (gw < word_num) ? g[(c * word_num + gw) * kLanes] : 0u;
+                    }
+                uint32_t st[NS + 2 * NC];
+#pragma unroll
+                for (int i = 0; i < NS; i++) st[i] = 0u;
+#pragma unroll
+                for (int i = 0; i < NC; i++) {
+                    st[NS + i] = carry[i * kLanes + lane];  // chunk 0
+                    st[NS + NC + i] = 0u;
+                }
+                uint32_t voff = static_cast<uint32_t>(lane * 4);
+                bitpal_block_rows_asm<NW>(st, P, voff, carry_base, uniform_u64(s),
+                                          __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+#pragma unroll
+                for (int i = 0; i < NC; i++) {
+                    const uint32_t word = tail_rows ? (st[NS + NC + i] << (32 - tail_rows)) : st[NS + NC + i];
+                    carry[((n_chunks - 1) * NC + i) * kLanes + lane] = word;
+                }
+                score += bitpal_column_sum<NW>(st, blk * NW, read_len);
+            }
+            out[static_cast<size_t>(q) * ld + static_cast<size_t>(group) * kLanes + lane] = static_cast<int16_t>(score);
+        }
+    }
+}
+
+namespace {
+
+// Narrowest instantiated block width that covers word_num words with the fewest blocks.
+inline int pick_block_nw(int word_num, int *n_blocks)
+{
+    const int blocks = (word_num + kBitpalBlockMax - 1) / kBitpalBlockMax;
+    const int need = (word_num + blocks - 1) / blocks;
+    const int nw = need < kBitpalBlockMin ? kBitpalBlockMin : need;
+    *n_blocks = (word_num + nw - 1) / nw;
+    return nw;
+}
+
+template <int NW>
+int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
+                   int64_t read_count, int ref_start, int ref_end, int word_num, int n_blocks, void *d_workspace,
+                   hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int stride = blocked_stream_layout(ref_len, nullptr, nullptr);
+    const size_t stream_bytes = (static_cast<size_t>(stride) * nq + 255) & ~static_cast<size_t>(255);
+    if (int rc = launch_pack_blocked(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
+    hipLaunchKernelGGL((bitpal_blocked_kernel<NW>), dim3(kBlockedBlocks), dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
+                       static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
+                       stride, n_blocks);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+inline int pick_q_tile(int nq, int64_t n_groups)
+{
+    int q_tile = 16;
+    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    return q_tile;
+}
+
+template <int NW>
+int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+              int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+              void *d_workspace, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    const int q_tile = pick_q_tile(nq, n_groups);
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("bitpal: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    hipLaunchKernelGGL(bitpal_asm_kernel<NW>, grid, dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                       read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)));
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+}  // namespace
+
+const char *set_kernel_name(int word_num)
+{
+    static thread_local char name[64];
+    if (word_num > kBitpalMaxPlain) {
+        int n_blocks = 0;
+        snprintf(name, sizeof name, "bitpal_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
+        return name;
+    }
+    snprintf(name, sizeof name, "bitpal_asm_kernel<%d>", word_num);
+    return name;
+}
+
+int set_launch(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+               int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+               void *d_workspace, hipStream_t stream)
+{
+    if (word_num > kBitpalMaxPlain) {
+        int n_blocks = 0;
+        switch (pick_block_nw(word_num, &n_blocks)) {
+#define X(N)                                                                                     \
+    case N:                                                                                      \
+        return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
+                                 ref_end, word_num, n_blocks, d_workspace, stream);
+            BGSA_BITPAL_BLOCK_WIDTHS(X)
+#undef X
+        default: break;
+        }
+    }
+    switch (word_num) {
+#define X(N)                                                                                    \
+    case N:                                                                                     \
+        return launch_nw<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,         \
+                            ref_start, ref_end, word_num, d_workspace, stream);
+        BGSA_BITPAL_PLAIN_WIDTHS(X)
+#undef X
+    default:
+        set_error_text("bitpal: no kernel for this word count");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+}

@@ -113,6 +113,34 @@ int bgsa_hip_select_algorithm(int algo)
 }
 int bgsa_hip_current_algorithm(void) { return g_algo; }
 
+int bgsa_hip_select_scores(int match, int mismatch, int gap)
+{
+    if (!bitpal_find_set(match, mismatch, gap)) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "select_scores: no BitPAl kernels compiled for %d / %d / %d (make BITPAL_SETS=...)",
+                 match, mismatch, gap);
+        set_error_text(msg);
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (int rc = bgsa_hip_select_algorithm(BGSA_ALGO_BITPAL)) return rc;
+    match_score = match; mismatch_score = mismatch; gap_score = gap;
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_score_set_count(void) { return bitpal_set_count(); }
+int bgsa_hip_score_set(int index, int *match, int *mismatch, int *gap, int *valu_per_word)
+{
+    const BitpalSet *s = bitpal_set_at(index);
+    if (!s) {
+        set_error_text("score_set: index out of range");
+        return BGSA_HIP_EINVAL;
+    }
+    if (match) *match = s->match;
+    if (mismatch) *mismatch = s->mismatch;
+    if (gap) *gap = s->gap;
+    if (valu_per_word) *valu_per_word = s->valu_per_word;
+    return BGSA_HIP_OK;
+}
+
 int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k)
 {
     switch (algo) {
@@ -243,10 +271,12 @@ size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queri
 {
     if (ref_len <= 0 || n_queries <= 0) return 0;
     if (read_len > 0 && beyond_registers(algo, (read_len + 31) / 32)) {  // column blocks: streams + carry buffers
-        const int chains = algo == BGSA_ALGO_BITPAL ? 13 : 3;
+        const int chains = algo == BGSA_ALGO_BITPAL ? bitpal_current_set()->chains : 3;  // non-null: beyond_registers() saw it
         const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
                                blocked_carry_bytes(ref_len, chains);
-        const size_t in_memory = long_state_bytes(algo, (read_len + 31) / 32);  // BGSA_*_IMPL=c
+        // the A/B state-in-memory kernels (BGSA_MYERS_IMPL=c / BGSA_BITPAL_IMPL=c) keep the DP state here
+        const char *ab = getenv(algo == BGSA_ALGO_BITPAL ? "BGSA_BITPAL_IMPL" : "BGSA_MYERS_IMPL");
+        const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
         return blocked > in_memory ? blocked : in_memory;
     }
     if (algo == BGSA_ALGO_BANDED)  // event tokens make the stream longer; k = 1 is the longest

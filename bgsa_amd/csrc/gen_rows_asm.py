@@ -34,8 +34,8 @@ import rows_ir as R  # noqa: E402
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8]
 MYERS_PLANES_NW = [12, 16, 20, 24, 28, 32]
 MYERS_BLOCK_NW = [20, 24, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
-BITPAL_NW = [1, 2, 3, 4, 5, 6, 7, 8]
-BITPAL_BLOCK_NW = [5, 6, 7, 8]  # block widths of the > 256 bp kernel
+BITPAL_VGPR_BUDGET = 224        # state + masks + temporaries a plain BitPAl kernel may hold
+BITPAL_BLOCK_VGPR_BUDGET = 200  # same + carry words for a column-block kernel (hipcc adds ~25 around the asm)
 
 # Scalar scratch registers, hard-coded and declared as clobbers (inline asm cannot name the
 # halves of a 64-bit "s" operand, and the jump needs lo/hi arithmetic).
@@ -350,9 +350,22 @@ def gen_blocked_function(fn_name: str, nw: int, body: R.Body, n_base: int, n_cha
     asm.append("L_refill_end_%=:")
     asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
     asm.append(f"L_body7_%=:")  # CARRY: chunk j out, chunk j+1 in ([chunk][chain][64 lanes] dwords)
-    asm += [f"global_store_dword %[voff], %[s{cout[i]}], {S_CB} offset:{256 * i}" for i in range(n_chains)]
-    asm.append(f"v_add_u32 %[voff], 0x{256 * n_chains:x}, %[voff]")
-    asm += [f"global_load_dword %[s{cin[i]}], %[voff], {S_CB} offset:{256 * i} sc1" for i in range(n_chains)]
+    # (the instruction offset is 13-bit signed: beyond 15 chains voff itself moves on in between)
+    moved = 0
+    for i in range(n_chains):
+        if 256 * i - moved > 3840:
+            asm.append(f"v_add_u32 %[voff], 0x{256 * i - moved:x}, %[voff]")
+            moved = 256 * i
+        asm.append(f"global_store_dword %[voff], %[s{cout[i]}], {S_CB} offset:{256 * i - moved}")
+    asm.append(f"v_add_u32 %[voff], 0x{256 * n_chains - moved:x}, %[voff]")
+    moved = 0
+    for i in range(n_chains):
+        if 256 * i - moved > 3840:
+            asm.append(f"v_add_u32 %[voff], 0x{256 * i - moved:x}, %[voff]")
+            moved = 256 * i
+        asm.append(f"global_load_dword %[s{cin[i]}], %[voff], {S_CB} offset:{256 * i - moved} sc1")
+    if moved:
+        asm.append(f"v_add_u32 %[voff], 0x{(-moved) & 0xFFFFFFFF:x}, %[voff]")
     asm.append("s_waitcnt vmcnt(0)")
     asm += dispatch()
     asm.append("L_done_%=:")
@@ -389,6 +402,64 @@ __device__ __forceinline__ void {fn_name}<{nw}>(uint32_t (&state)[{n_state}], {m
 """
 
 
+def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int]]:
+    """Kernel widths for one score set: plain kernels (state in registers for the whole subject) for
+    1..P words and column-block kernels for the four widths up to W, the widest that fit the VGPR
+    budget (at most 8: beyond that fewer waves per SIMD cost more than wider blocks gain)."""
+    def plain_regs(nw):
+        return sc.planes * nw + 5 * nw + R.bitpal_body(nw, sc).allocate_temps()[1]
+
+    def block_regs(nw):
+        body, _ = R.make_blocked(R.bitpal_body(nw, sc), sc.planes * nw)
+        return sc.planes * nw + 5 * nw + body.allocate_temps()[1] + 2 * sc.chains + 2
+
+    plain = max(nw for nw in range(1, 9) if plain_regs(nw) <= BITPAL_VGPR_BUDGET)
+    wide = max(nw for nw in range(1, 9) if block_regs(nw) <= BITPAL_BLOCK_VGPR_BUDGET)
+    return list(range(1, plain + 1)), list(range(max(1, wide - 3), wide + 1))
+
+
+def bitpal_inc_text(sc: R.BitpalScores) -> str:
+    """The generated header of one BitPAl score set: constants + row loops of every width."""
+    B, NC = sc.planes, sc.chains
+    plain, blocks = bitpal_widths(sc)
+    per_word = R.bitpal_body(1, sc).valu_count()
+    case = lambda ws: " ".join(f"X({w})" for w in ws)
+    parts = ["// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n",
+             f"// BitPAl packed, match {sc.match} / mismatch {sc.mismatch} / gap {sc.gap}: {B} planes per word (two's complement of\n"
+             f"// -(dH - gap), values 0..{sc.C}), {sc.K} value classes above the mismatch class {sc.D}, {NC} carry chains,\n"
+             f"// {per_word} VALU per (row, word).\n"
+             f"constexpr int kBitpalMatch = {sc.match}, kBitpalMismatch = {sc.mismatch}, kBitpalGap = {sc.gap};\n"
+             f"constexpr int kBitpalPlanes = {B};\n"
+             f"constexpr int kBitpalChains = {NC};\n"
+             f"constexpr int kBitpalValuPerWord = {per_word};\n"
+             f"constexpr int kBitpalMaxPlain = {plain[-1]};   // widest kernel that keeps the whole subject in registers\n"
+             f"constexpr int kBitpalBlockMin = {blocks[0]}, kBitpalBlockMax = {blocks[-1]};   // column-block widths\n"
+             f"constexpr int kBitpalWeights[{B}] = {{{', '.join(str(x) for x in sc.weights())}}};   // score weight of a set bit per plane\n"
+             f"#define BGSA_BITPAL_PLAIN_WIDTHS(X) {case(plain)}\n"
+             f"#define BGSA_BITPAL_BLOCK_WIDTHS(X) {case(blocks)}\n"
+             "// All rows of one query against one group.  state[w*kBitpalPlanes+i] = plane i of word w\n"
+             "// (plane kBitpalPlanes-1 = sign); P[c][w] = match mask of character class c.\n"
+             "template <int NW>\n"
+             "__device__ __forceinline__ void bitpal_rows_asm(uint32_t (&state)[kBitpalPlanes * NW],\n"
+             "                                                const uint32_t (&P)[5][NW],\n"
+             "                                                const unsigned long long stream, const int n_windows);\n"]
+    for nw in plain:
+        parts.append(gen_function("bitpal_rows_asm", f"{nw}", R.bitpal_body(nw, sc), B * nw, nw))
+    parts.append("\n// One column block of a subject too long for the plain kernels (rows_ir.py: make_blocked(bitpal_body)).\n"
+                 "// state = planes x NW, then the carry-in words, then the carry-out words; voff / carry_base as\n"
+                 "// in myers_block_rows_asm ([32-row chunk][chain][64 lanes] dwords).\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ void bitpal_block_rows_asm(uint32_t (&state)[kBitpalPlanes * NW + 2 * kBitpalChains],\n"
+                 "                                                      const uint32_t (&P)[5][NW], uint32_t &voff,\n"
+                 "                                                      const unsigned long long carry_base,\n"
+                 "                                                      const unsigned long long stream, const int n_windows);\n")
+    for nw in blocks:
+        blocked, init = R.make_blocked(R.bitpal_body(nw, sc), B * nw)
+        assert len(init) == NC and not any(init)  # every BitPAl chain starts with carry-in 0
+        parts.append(gen_blocked_function("bitpal_block_rows_asm", nw, blocked, B * nw, NC, 0, nw))
+    return "".join(parts)
+
+
 def main() -> int:
     here = Path(__file__).resolve().parent
     head = "// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n"
@@ -421,30 +492,8 @@ def main() -> int:
     for nw in MYERS_BLOCK_NW:
         parts.append(gen_blocked_function("myers_block_rows_asm", nw, R.myers_block_body(nw), 2 * nw, 3, 3 * nw, 0))
     (here / "myers_rows_gen.inc").write_text("".join(parts))
-    # ---- BitPAl -------------------------------------------------------------------------------
-    parts = [head,
-             "// All rows of one query against one group.  state[w*5+i] = plane i (weights 1,2,4,8,16)\n"
-             "// of word w; P[c][w] = match mask of character class c.\n"
-             "template <int NW>\n"
-             "__device__ __forceinline__ void bitpal_rows_asm(uint32_t (&state)[5 * NW],\n"
-             "                                                const uint32_t (&P)[5][NW],\n"
-             "                                                const unsigned long long stream, const int n_windows);\n"]
-    for nw in BITPAL_NW:
-        parts.append(gen_function("bitpal_rows_asm", f"{nw}", R.bitpal_body(nw), 5 * nw, nw))
-    parts.append("\n// One column block of a subject longer than 256 bp (rows_ir.py: make_blocked(bitpal_body)).\n"
-                 "// state = 5 planes x NW, then 13 carry-in words, then 13 carry-out words; voff / carry_base as\n"
-                 "// in myers_block_rows_asm ([32-row chunk][13 chains][64 lanes] dwords).\n"
-                 f"constexpr int kBitpalChains = {len(R.make_blocked(R.bitpal_body(1), 5)[1])};\n"
-                 "template <int NW>\n"
-                 "__device__ __forceinline__ void bitpal_block_rows_asm(uint32_t (&state)[5 * NW + 2 * kBitpalChains],\n"
-                 "                                                      const uint32_t (&P)[5][NW], uint32_t &voff,\n"
-                 "                                                      const unsigned long long carry_base,\n"
-                 "                                                      const unsigned long long stream, const int n_windows);\n")
-    for nw in BITPAL_BLOCK_NW:
-        blocked, init = R.make_blocked(R.bitpal_body(nw), 5 * nw)
-        assert not any(init)  # every BitPAl chain starts with carry-in 0
-        parts.append(gen_blocked_function("bitpal_block_rows_asm", nw, blocked, 5 * nw, len(init), 0, nw))
-    (here / "bitpal_rows_gen.inc").write_text("".join(parts))
+    # ---- BitPAl, default scores (other score sets: gen_bitpal_sets.py) ------------------------
+    (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))
     # ---- banded -------------------------------------------------------------------------------
     (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(True))
     return 0

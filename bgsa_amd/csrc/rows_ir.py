@@ -573,126 +573,267 @@ def _banded_simulate64(subjects: np.ndarray, query: np.ndarray, k: int) -> np.nd
 
 
 # =================================================================================================
-# BitPAl packed, match 2 / mismatch -3 / gap -5 (reference original/BGSA_AVX2/align_core.c:183-428)
+# BitPAl packed for any integer scores (match M > mismatch I >= 2*gap G, G < 0): the scheme the
+# reference's generator emits per score set (generator/.../BitPAlGenerator.java:151-534 packed form,
+# ScoreMsg.java:23-31 for the value ranges), restated on normalised differences.
+#
+#   u_j = dH(row above, column j) - G   in [0, C],  C = M - 2G      (stored as B-bit two's complement of -u)
+#   v_j = dV(column j)            - G   in [0, C]
+#   v_j = max(0, w_j - u_j),  w_j = C at a match, else max(D, v_{j-1}),  D = I - 2G
+#   new u_j = max(0, max(W_j, u_j) - v_{j-1}),  W_j = C at a match, D otherwise
+#
+# Only the K = M - I values above D survive a mismatch unchanged, so the row resolves the chain
+# v_{j-1} -> v_j per value class C, C-1, ..., D+1 with one add-with-carry run propagation each (the
+# value is kept across columns with u = 0) and treats everything else as class D.
 # =================================================================================================
 
-def bitpal_body(nw: int) -> Body:
-    """State layout: S[w*5 + i] = plane i (weights 1,2,4,8,16) of word w; E[w] = match mask.
+@dataclass(frozen=True)
+class BitpalScores:
+    match: int = 2
+    mismatch: int = -3
+    gap: int = -5
 
-    The planes hold, per subject column, the 5-bit two's complement of -(dH + 5): 0 = dH -5 ...
-    0b11001 = dH +2 (align_core.c:191-214).  Words are full 32-bit here (the reference keeps bit 31
-    as a software carry): all fourteen inter-word carries of align_core.c:176-179 — five adds,
-    four seed shifts, the plane shifts — ride VCC chains, one chain per phase.
-    """
+    def __post_init__(self):
+        if not (self.match > self.mismatch and self.mismatch >= 2 * self.gap and self.gap < 0):
+            raise ValueError("BitPAl needs match > mismatch >= 2*gap and gap < 0")
+
+    @property
+    def C(self) -> int: return self.match - 2 * self.gap          # largest normalised difference
+    @property
+    def D(self) -> int: return self.mismatch - 2 * self.gap       # the mismatch class
+    @property
+    def K(self) -> int: return self.match - self.mismatch         # value classes above D
+    @property
+    def nb(self) -> int: return self.C.bit_length()               # magnitude planes
+    @property
+    def planes(self) -> int: return self.nb + 1                   # + sign plane
+    @property
+    def chains(self) -> int: return 1 + 2 * (self.K - 1) + self.nb
+    @property
+    def tag(self) -> str:
+        f = lambda v: f"m{-v}" if v < 0 else f"{v}"
+        return f"{f(self.match)}_{f(self.mismatch)}_{f(self.gap)}"
+
+    def weights(self) -> tuple:
+        """Per-plane weight of a set bit in the final score: u = 2^(B-1) p_(B-1) - sum 2^i p_i."""
+        return tuple(-(1 << i) for i in range(self.nb)) + (1 << self.nb,)
+
+
+BITPAL_DEFAULT = BitpalScores(2, -3, -5)
+
+
+class _Bool:
+    """Boolean-expression helper over a Body with common-subexpression sharing per word."""
+
+    def __init__(self, body: Body, prefix: str):
+        self.b = body
+        self.memo = {}
+        self.n = 0
+        self.prefix = prefix
+
+    def _name(self, hint):
+        self.n += 1
+        return f"{hint}{self.prefix}_{self.n}"
+
+    def op3(self, fn, a, b_, c, hint="x"):
+        # canonical operand order, so that e.g. OR3(p0, p1, p2) and OR3(p2, p1, p0) are one instruction
+        order = sorted(range(3), key=lambda i: (a, b_, c)[i])
+        ops = [(a, b_, c)[i] for i in order]
+
+        def g(x0, x1, x2, order=order, fn=fn):
+            args = [None, None, None]
+            for pos, i in enumerate(order):
+                args[i] = (x0, x1, x2)[pos]
+            return fn(*args)
+
+        key = (tt(g), *ops)
+        if key not in self.memo:
+            self.memo[key] = self.b.BITOP3(self._name(hint), ops[0], ops[1], ops[2], g)
+        return self.memo[key]
+
+    def op2(self, kind, a, b_, hint="x"):
+        key = (kind, a, b_)
+        if key not in self.memo:
+            self.memo[key] = getattr(self.b, kind)(self._name(hint), a, b_)
+        return self.memo[key]
+
+    def or_all(self, names, hint="o"):
+        names = list(names)
+        while len(names) > 1:
+            if len(names) == 2:
+                return self.op2("OR", names[0], names[1], hint)
+            merged = self.op3(lambda a, b_, c: a | b_ | c, names[0], names[1], names[2], hint)
+            names = [merged] + names[3:]
+        return names[0]
+
+    def and_pattern(self, planes, bits, hint="z"):
+        """AND over planes of (plane if bit else ~plane); planes given MSB first.  Chunks are taken
+        from the MSB side so that patterns sharing their high bits share the partial products."""
+        n = len(planes)
+        lit = lambda x, bit: x if bit else ~x
+        first = 3 if n >= 3 and (n - 3) % 2 == 0 else 2
+        if first == 3:
+            b0, b1, b2 = bits[:3]
+            cur = self.op3(lambda a, b_, c: lit(a, b0) & lit(b_, b1) & lit(c, b2), planes[0], planes[1], planes[2], hint)
+        else:
+            b0, b1 = bits[:2]
+            cur = self.op3(lambda a, b_, c: lit(a, b0) & lit(b_, b1), planes[0], planes[1], planes[1], hint)
+        i = first
+        while i < n:
+            b0, b1 = bits[i], bits[i + 1]
+            cur = self.op3(lambda a, b_, c: a & lit(b_, b0) & lit(c, b1), cur, planes[i], planes[i + 1], hint)
+            i += 2
+        return cur
+
+
+def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
+    """Row body for `nw` words.  State S[w*B + i] = plane i of word w (B = sc.planes, plane B-1 the
+    sign); E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed
+    shift and its run, then the nb plane shifts — sc.chains in all."""
+    B, nb, C, D, K = sc.planes, sc.nb, sc.C, sc.D, sc.K
     b = Body()
-    H = lambda w, i: f"S{w * 5 + i}"
+    H = lambda w, i: f"S{w * B + i}"
     E = lambda w: f"E{w}"
     t = lambda name, w: f"{name}_{w}"
     W = range(nw)
+    full = (1 << B) - 1
+    z = {}      # (value of u, word) -> one-hot mask name
+    anym = {}   # word -> mismatch columns whose u <= D
+    dv = {}     # (class offset c, word) -> columns whose incoming v is C - c (c = 0: or a match)
 
-    # ---- decode dH classes (:191-214) + phase 1: dV = +7 run propagation (:216-223) ----------
+    # ---- decode the u classes the seeds need, the "u <= D" mask, and the top-class run ----------
     for w in W:
-        b.AND(t("top", w), H(w, 4), H(w, 3))
-        b.BITOP3(t("o3", w), H(w, 2), H(w, 1), H(w, 0), lambda a, b_, c: a | b_ | c)
-        b.BITOP3(t("neg5", w), H(w, 4), H(w, 3), t("o3", w), lambda a, b_, c: ~(a | b_ | c))
-        b.AND(t("bb", w), t("top", w), H(w, 2))                                   # 111xx
-        b.BITOP3(t("neg1", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & ~h2 & ~h1)
-        b.BITOP3(t("neg2", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & ~h2 & h1)
-        b.BITOP3(t("neg3", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & h2 & ~h1)
-        b.BITOP3(t("neg4", w), t("bb", w), H(w, 1), H(w, 0), lambda a, h2, h1: a & h2 & h1)
-        # columns holding any legal class, restricted to mismatches (:368-377):
-        # classes +2..0 = 110xx with xx != 00, classes -1..-4 = 111xx, class -5 = 00000
-        b.AND(t("vab", w), t("top", w), t("o3", w))
-        b.BITOP3(t("any", w), t("vab", w), t("neg5", w), E(w), lambda a, n5, e: (a | n5) & ~e)
-        # dV=+7: seeds where dH=-5 meets a match, carried along the remaining dH=-5 run
-        b.AND(t("seed", w), t("neg5", w), E(w))
-        b.BITOP3(t("run", w), t("neg5", w), E(w), E(w), lambda n5, e, _e: n5 & ~e)
-        (b.ADD_CO if w == 0 else b.ADDC)(t("sum", w), t("seed", w), t("neg5", w))
-        b.BITOP3(t("dv7m", w), t("sum", w), t("run", w), E(w), lambda s, r, e: (s ^ r) | e)
+        bx = _Bool(b, f"d{w}")
+        msb_first = [H(w, i) for i in range(B - 1, -1, -1)]
+        low = bx.or_all([H(w, i) for i in range(B - 2)], "lo") if B > 3 else H(w, 0)
+        z0 = bx.op3(lambda a, b_, c: ~(a | b_ | c), low, H(w, B - 2), H(w, B - 1), "z0")   # u == 0
+        for x in range(1, K):
+            pat = (full + 1 - x) & full
+            z[x, w] = bx.and_pattern(msb_first, [(pat >> i) & 1 for i in range(B - 1, -1, -1)])
+        # u <= D  <=>  u == 0 or stored value >= 2^B - D: constant comparator from the LSB up
+        # (r = "the bits seen so far are >= the constant's"; a one bit ANDs the plane in, a zero ORs it)
+        if D > 0:
+            t0 = (full + 1 - D) & full
+            step = lambda rv, p, bit: (p & rv) if bit else (p | rv)
+            i = 0
+            while not (t0 >> i) & 1:      # trailing zero bits of the constant: always satisfied
+                i += 1
+            r = H(w, i)
+            i += 1
+            while i < B:
+                b0 = (t0 >> i) & 1
+                if i + 1 < B:
+                    b1 = (t0 >> (i + 1)) & 1
+                    r = bx.op3(lambda x1, x0, rv, b0=b0, b1=b1: step(step(rv, x0, b0), x1, b1), H(w, i + 1), H(w, i), r, "ge")
+                    i += 2
+                else:
+                    r = bx.op2("AND" if b0 else "OR", H(w, i), r, "ge")
+                    i += 1
+            anym[w] = bx.op3(lambda ge, z_, e: (ge | z_) & ~e, r, z0, E(w), "any")
+        else:
+            anym[w] = bx.op3(lambda z_, e, _e: z_ & ~e, z0, E(w), E(w), "any")
+        b.AND(t("seed", w), z0, E(w))
+        b.BITOP3(t("run", w), z0, E(w), E(w), lambda z_, e, _e: z_ & ~e)
+        (b.ADD_CO if w == 0 else b.ADDC)(t("sum", w), t("seed", w), z0)
+        dv[0, w] = b.BITOP3(t("dvtop", w), t("sum", w), t("run", w), E(w), lambda s, r, e: (s ^ r) | e)
 
-    def shifted_run(seed_name, out_name):
-        """(:229-238) seed << 1 across words, added to the run with carry, toggled bits & ~match."""
-        for w in W:  # shift chain
+    def shifted_run(seed_name, c):
+        for w in W:
             (b.ADD_CO if w == 0 else b.ADDC)(t(seed_name, w), t(seed_name, w), t(seed_name, w))
-            if w + 1 < nw:
-                pass
-        for w in W:  # add chain
-            (b.ADD_CO if w == 0 else b.ADDC)(t("s_" + out_name, w), t(seed_name, w), t("run", w))
-            b.BITOP3(t(out_name, w), t("s_" + out_name, w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
+        for w in W:
+            (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(seed_name, w), t("run", w))
+            dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
 
-    # ---- dV = +6 (:224-238) ----------------------------------------------------------------------
-    for w in W:
-        b.AND(t("seed6", w), t("neg4", w), t("dv7m", w))
-    shifted_run("seed6", "dv6")
-    # ---- dV = +5 (:240-250) ----------------------------------------------------------------------
-    for w in W:
-        b.AND(t("seed5", w), t("neg3", w), t("dv7m", w))
-        b.BITOP3(t("seed5", w), t("neg4", w), t("dv6", w), t("seed5", w), lambda a, b_, c: (a & b_) | c)
-    shifted_run("seed5", "dv5")
-    # ---- dV = +4 (:252-264) ----------------------------------------------------------------------
-    for w in W:
-        b.AND(t("seed4", w), t("neg2", w), t("dv7m", w))
-        b.BITOP3(t("seed4", w), t("neg3", w), t("dv6", w), t("seed4", w), lambda a, b_, c: (a & b_) | c)
-        b.BITOP3(t("seed4", w), t("neg4", w), t("dv5", w), t("seed4", w), lambda a, b_, c: (a & b_) | c)
-    shifted_run("seed4", "dv4")
-    # ---- dV = +3 (:266-280) ----------------------------------------------------------------------
-    for w in W:
-        b.AND(t("seed3", w), t("neg1", w), t("dv7m", w))
-        b.BITOP3(t("seed3", w), t("neg2", w), t("dv6", w), t("seed3", w), lambda a, b_, c: (a & b_) | c)
-        b.BITOP3(t("seed3", w), t("neg3", w), t("dv5", w), t("seed3", w), lambda a, b_, c: (a & b_) | c)
-        b.BITOP3(t("seed3", w), t("neg4", w), t("dv4", w), t("seed3", w), lambda a, b_, c: (a & b_) | c)
-    shifted_run("seed3", "dv3")
+    # ---- classes C-1 .. D+1: value C-c appears where an incoming class C-x meets u = c-x ----------
+    for c in range(1, K):
+        for w in W:
+            b.AND(t(f"seed{c}", w), z[c, w], dv[0, w])
+            for x in range(1, c):
+                b.BITOP3(t(f"seed{c}", w), z[c - x, w], dv[x, w], t(f"seed{c}", w), lambda a, b_, acc: (a & b_) | acc)
+        shifted_run(f"seed{c}", c)
 
-    # ---- encode dV (:281-297), dH + dV clamped at zero (:299-331) --------------------------------
+    # ---- w planes, v = max(0, w - u) -----------------------------------------------------------------
+    lit = {"reg": lambda x: x, "not": lambda x: ~x, "zero": lambda x: 0, "one": lambda x: 0xFF}
     for w in W:
-        b.BITOP3(t("x", w), t("dv7m", w), t("dv6", w), t("dv5", w), lambda a, b_, c: a | b_ | c)
-        b.BITOP3(t("rest", w), t("x", w), t("dv4", w), t("dv3", w), lambda a, b_, c: ~(a | b_ | c))
-        b.BITOP3(t("v0", w), t("rest", w), t("dv4", w), t("dv6", w), lambda a, b_, c: a | b_ | c)
-        b.BITOP3(t("v1", w), t("rest", w), t("dv5", w), t("dv6", w), lambda a, b_, c: a | b_ | c)
-        b.OR(t("v2", w), t("rest", w), t("dv7m", w))
-        # v3 = ~rest, v4 = 0
-        b.XOR(t("s0", w), H(w, 0), t("v0", w))
-        b.AND(t("c", w), H(w, 0), t("v0", w))
-        b.BITOP3(t("s1", w), H(w, 1), t("v1", w), t("c", w), lambda a, b_, c: a ^ b_ ^ c)
-        b.BITOP3(t("c", w), H(w, 1), t("v1", w), t("c", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
-        b.BITOP3(t("s2", w), H(w, 2), t("v2", w), t("c", w), lambda a, b_, c: a ^ b_ ^ c)
-        b.BITOP3(t("c", w), H(w, 2), t("v2", w), t("c", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
-        b.BITOP3(t("s3", w), H(w, 3), t("rest", w), t("c", w), lambda a, r, c: a ^ ~r ^ c)
-        b.BITOP3(t("c", w), H(w, 3), t("rest", w), t("c", w), lambda a, r, c: (a & ~r) | (a & c) | (~r & c))
-        b.XOR(t("s4", w), H(w, 4), t("c", w))
-        for i in range(4):
-            b.BITOP3(t(f"s{i}", w), t(f"s{i}", w), t("s4", w), t("s4", w), lambda s, k, _k: s & ~k)
+        bx = _Bool(b, f"w{w}")
+        cls_mask = {C - c: dv[c, w] for c in range(K)}
+        planes = []   # (kind, name): plane i of w is name / ~name / 0 / 1
+        for i in range(nb):
+            have = [val for val in cls_mask if (val >> i) & 1]
+            lack = [val for val in cls_mask if not (val >> i) & 1]
+            if (D >> i) & 1:   # class D (all the remaining columns) has the bit: complement of the lacking classes
+                planes.append(("not", bx.or_all([cls_mask[v] for v in lack], "wl")) if lack else ("one", None))
+            else:
+                planes.append(("reg", bx.or_all([cls_mask[v] for v in have], "wh")) if have else ("zero", None))
+        carry = None
+        for i in range(B):
+            kind, name = planes[i] if i < nb else ("zero", None)
+            f = lit[kind]
+            src = name if name is not None else H(w, i)
+            last = i == B - 1
+            if carry is None:
+                b.BITOP3(t(f"s{i}", w), H(w, i), src, src, lambda h, x, _x, f=f: h ^ f(x))
+                if not last:
+                    carry = b.BITOP3(t("c", w), H(w, i), src, src, lambda h, x, _x, f=f: h & f(x))
+            else:
+                b.BITOP3(t(f"s{i}", w), H(w, i), src, carry, lambda h, x, cy, f=f: h ^ f(x) ^ cy)
+                if not last:
+                    carry = b.BITOP3(t("c", w), H(w, i), src, carry,
+                                     lambda h, x, cy, f=f: (h & f(x)) | (h & cy) | (f(x) & cy))
+        for i in range(nb):
+            b.BITOP3(t(f"s{i}", w), t(f"s{i}", w), t(f"s{B - 1}", w), t(f"s{B - 1}", w), lambda s, k, _k: s & ~k)
 
-    # ---- new dH seed planes from match / mismatch (:368-391); they only need H, any, E -----------
+    # ---- -max(W, u): -C at a match, -D at a mismatch with u <= D, else the stored -u ---------------
+    negC, negD = (full + 1 - C) & full, (full + 1 - D) & full
+
     def seed_planes(w):
-        b.BITOP3(t("g0", w), H(w, 0), t("any", w), E(w), lambda h, a, e: (h | a) & ~e)
-        b.BITOP3(t("g1", w), H(w, 1), t("any", w), E(w), lambda h, a, e: h & ~a & ~e)
-        b.BITOP3(t("g2", w), H(w, 2), t("any", w), E(w), lambda h, a, e: (h & ~a) | e)
-        b.BITOP3(t("g3", w), H(w, 3), t("any", w), E(w), lambda h, a, e: (h | a) & ~e)
-        b.BITOP3(t("g4", w), H(w, 4), t("any", w), E(w), lambda h, a, e: h | a | e)
+        for i in range(B):
+            cb, db = 0xFF * ((negC >> i) & 1), 0xFF * ((negD >> i) & 1)
+            b.BITOP3(t(f"g{i}", w), H(w, i), anym[w], E(w),
+                     lambda h, a, e, cb=cb, db=db: (cb & e) | (db & a & ~e) | (h & ~a & ~e))
 
-    # ---- shift the clamped sum one column up (:333-360): four chains; the seed-plane work is
-    #      interleaved so that consecutive links of a chain are two instructions apart ----------------
-    for i in range(4):
+    # ---- v one column up: nb shift chains, the seed-plane work interleaved into the first -----------
+    for i in range(nb):
         for w in W:
             (b.ADD_CO if w == 0 else b.ADDC)(t(f"s{i}", w), t(f"s{i}", w), t(f"s{i}", w))
             if i == 0:
                 seed_planes(w)
 
-    # ---- add the shifted sum to the seed planes and mask by sign (:393-426) ----------------------
+    # ---- new -u = g + v_in, clamped at zero from above (a positive sum means u would be negative) --
     for w in W:
-        b.XOR(t("r0", w), t("g0", w), t("s0", w))
-        b.AND(t("k", w), t("g0", w), t("s0", w))
-        b.BITOP3(t("r1", w), t("g1", w), t("s1", w), t("k", w), lambda a, b_, c: a ^ b_ ^ c)
-        b.BITOP3(t("k", w), t("g1", w), t("s1", w), t("k", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
-        b.BITOP3(t("r2", w), t("g2", w), t("s2", w), t("k", w), lambda a, b_, c: a ^ b_ ^ c)
-        b.BITOP3(t("k", w), t("g2", w), t("s2", w), t("k", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
-        b.BITOP3(t("r3", w), t("g3", w), t("s3", w), t("k", w), lambda a, b_, c: a ^ b_ ^ c)
-        b.BITOP3(t("k", w), t("g3", w), t("s3", w), t("k", w), lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
-        b.XOR(H(w, 4), t("g4", w), t("k", w))
-        for i in range(4):
-            b.AND(H(w, i), t(f"r{i}", w), H(w, 4))
+        carry = None
+        for i in range(B):
+            last = i == B - 1
+            dst = H(w, i) if last else t(f"r{i}", w)
+            if i < nb:
+                if carry is None:
+                    b.XOR(dst, t(f"g{i}", w), t(f"s{i}", w))
+                    carry = b.AND(t("k", w), t(f"g{i}", w), t(f"s{i}", w))
+                else:
+                    b.BITOP3(dst, t(f"g{i}", w), t(f"s{i}", w), carry, lambda a, b_, c: a ^ b_ ^ c)
+                    carry = b.BITOP3(t("k", w), t(f"g{i}", w), t(f"s{i}", w), carry,
+                                     lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
+            else:   # the sign plane of v_in is zero
+                b.XOR(dst, t(f"g{i}", w), carry)
+        for i in range(B - 1):
+            b.AND(H(w, i), t(f"r{i}", w), H(w, B - 1))
     return b
+
+
+def bitpal_scores_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT) -> list:
+    return [np.zeros(lanes, dtype=np.uint32) for _ in range(sc.planes * nw)]   # every column at dH = G
+
+
+def bitpal_scores_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalScores = BITPAL_DEFAULT) -> np.ndarray:
+    """S[m][n] = G*(m + n) + sum over subject columns of u."""
+    score = np.full(state[0].shape, sc.gap * (qlen + slen), dtype=np.int64)
+    B = sc.planes
+    for w in range(nw):
+        rem = slen - 32 * w
+        mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
+        for i, wt in enumerate(sc.weights()):
+            score += wt * np.bitwise_count(state[w * B + i] & mask).astype(np.int64)
+    return score.astype(np.int16)
 
 
 def make_blocked(body: Body, n_state: int):
@@ -729,23 +870,39 @@ def make_blocked(body: Body, n_state: int):
     return out, [c for _, c in chains]
 
 
-def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int) -> np.ndarray:
+def bitpal_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
+    """For the default scores this is the packed kernel of original/BGSA_AVX2/align_core.c:183-428
+    (same five planes, same two's complement of -(dH + 5)) at 76 fast-class VALU per word."""
+    return bitpal_scores_body(nw, sc)
+
+
+def bitpal_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT) -> list:
+    return bitpal_scores_init_state(nw, lanes, sc)
+
+
+def bitpal_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalScores = BITPAL_DEFAULT) -> np.ndarray:
+    return bitpal_scores_score(state, nw, qlen, slen, sc)
+
+
+def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int,
+                            sc: BitpalScores = BITPAL_DEFAULT) -> np.ndarray:
     """BitPAl over column blocks of nw_block words with carry words between blocks — the scheme of
     bitpal_blocked_kernel at toy scale.  Returns int16."""
     n, slen = subjects.shape
     qlen = len(query)
+    B = sc.planes
     nw_total = (slen + 31) // 32
     n_blocks = (nw_total + nw_block - 1) // nw_block
     peq = build_peq32(subjects, n_blocks * nw_block)
-    body, init = make_blocked(bitpal_body(nw_block), 5 * nw_block)
+    body, init = make_blocked(bitpal_body(nw_block, sc), B * nw_block)
     n_ch = len(init)
+    assert n_ch == sc.chains and not any(init)
     code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
     n_chunks = (qlen + 31) // 32
-    FULL = np.uint32(0xFFFFFFFF)
-    carry = [[np.full(n, FULL if init[k] else 0, np.uint32) for k in range(n_ch)] for _ in range(n_chunks)]
-    score = np.full(n, -5 * qlen - 5 * slen, dtype=np.int64)
-    weights = (-1, -2, -4, -8, 16)
-    base = 5 * nw_block
+    carry = [[np.zeros(n, np.uint32) for k in range(n_ch)] for _ in range(n_chunks)]
+    score = np.full(n, sc.gap * (qlen + slen), dtype=np.int64)
+    weights = sc.weights()
+    base = B * nw_block
     for blk in range(n_blocks):
         st = [np.zeros(n, np.uint32) for _ in range(base)] + [c.copy() for c in carry[0]] + \
              [np.zeros(n, np.uint32) for _ in range(n_ch)]
@@ -766,23 +923,7 @@ def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: i
             rem = slen - 32 * (blk * nw_block + w)
             mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
             for i, wt in enumerate(weights):
-                score += wt * np.bitwise_count(st[w * 5 + i] & mask).astype(np.int64)
-    return score.astype(np.int16)
-
-
-def bitpal_init_state(nw: int, lanes: int) -> list:
-    return [np.zeros(lanes, dtype=np.uint32) for _ in range(5 * nw)]  # all dH = -5 (:167-171)
-
-
-def bitpal_score(state: list, nw: int, qlen: int, slen: int) -> np.ndarray:
-    """(:433-471) score = -5*qlen + sum over subject columns of (16 b16 - 8 b8 - 4 b4 - 2 b2 - b1 - 5)."""
-    score = np.full(state[0].shape, -5 * qlen - 5 * slen, dtype=np.int64)
-    weights = (-1, -2, -4, -8, 16)
-    for w in range(nw):
-        rem = slen - 32 * w
-        mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
-        for i, wt in enumerate(weights):
-            score += wt * np.bitwise_count(state[w * 5 + i] & mask).astype(np.int64)
+                score += wt * np.bitwise_count(st[w * B + i] & mask).astype(np.int64)
     return score.astype(np.int16)
 
 

@@ -60,7 +60,7 @@ typedef struct _seq_t {
 enum {
     BGSA_ALGO_MYERS = 0,  /* unit-cost global edit distance, result = -distance (int16) */
     BGSA_ALGO_BANDED = 1, /* banded Myers filter, result = band distance or 127 (int8) */
-    BGSA_ALGO_BITPAL = 2, /* BitPAl packed match 2 / mismatch -3 / gap -5 (int16) */
+    BGSA_ALGO_BITPAL = 2, /* BitPAl packed, match 2 / mismatch -3 / gap -5 unless bgsa_hip_select_scores() (int16) */
 };
 
 /* The five ints every align_core.c exports (reference original/BGSA_CPU/align_core.c:13-17);
@@ -85,6 +85,20 @@ void free_mem(void *mem);
 
 int bgsa_hip_select_algorithm(int algo);
 int bgsa_hip_current_algorithm(void);
+
+/* BitPAl with other integer scores (match > mismatch >= 2*gap, gap < 0).  The reference emits one
+ * align_core.c per score set with its generator (`java -jar generator.jar -M -I -G`, README.md:26-82,
+ * generator/.../BitPAlGenerator.java) and is rebuilt for it; this library is built with a list of
+ * sets (`make -C bgsa_amd/csrc BITPAL_SETS="2,-3,-5 1,-3,-2 ..."`, gen_bitpal_sets.py) and picks the
+ * kernels of the set that match_score / mismatch_score / gap_score name at call time.
+ * bgsa_hip_select_scores() = select BGSA_ALGO_BITPAL and set the three ints, or
+ * BGSA_HIP_EUNSUPPORTED (ints unchanged) if that set was not compiled in; scoring with ints that
+ * name no compiled set fails the same way.  bgsa_hip_score_set() enumerates the compiled sets
+ * (index 0 = the reference's committed 2/-3/-5); valu_per_word = VALU instructions per (row, 32
+ * columns) of that set's kernel.  Any out-pointer may be NULL. */
+int bgsa_hip_select_scores(int match, int mismatch, int gap);
+int bgsa_hip_score_set_count(void);
+int bgsa_hip_score_set(int index, int *match, int *mismatch, int *gap, int *valu_per_word);
 
 /* word_num for the selected algorithm (what cal_<arch>.c computes at cal_cpu.c:252-256, banded
  * cal_cpu.c:253-254). */

@@ -179,3 +179,43 @@ def test_column_block_query_stream(L, qlen):
         want.append(int(row[r]))
     assert tokens == want and (buf[-8:] == 5).all()
     assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_MYERS, qlen, 2000, 2) >= 2 * n
+
+
+def test_score_sets_are_listed_and_selectable(L):
+    sets = B.score_sets()
+    assert sets[0] == (2, -3, -5)          # the reference's committed instance is always index 0
+    assert len(set(sets)) == len(sets)
+    for m, x, g in sets:
+        assert m > x >= 2 * g and g < 0
+        assert L.bgsa_hip_select_scores(m, x, g) == 0
+        assert L.bgsa_hip_current_algorithm() == B.ALGO_BITPAL
+        assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [m, x, g]
+    assert L.bgsa_hip_score_set(len(sets), None, None, None, None) != 0
+    assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+
+
+def test_unknown_score_set_fails_loudly_and_changes_nothing(L):
+    assert L.bgsa_hip_select_algorithm(B.ALGO_BITPAL) == 0
+    assert L.bgsa_hip_select_scores(9, -9, -9) != 0
+    assert b"BITPAL_SETS" in L.bgsa_hip_last_error()
+    assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [2, -3, -5]
+    # a maintainer writing the three ints directly (they are plain globals in the reference) gets
+    # the same refusal when scoring is attempted
+    ctypes.c_int.in_dll(L, "match_score").value = 9
+    try:
+        assert L.bgsa_hip_kernel_name(B.ALGO_BITPAL, 5).startswith(b"bitpal: score set not compiled")
+    finally:
+        assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+
+
+def test_workspace_follows_the_selected_score_set(L):
+    # carry buffers scale with the chain count of the set; plain kernels only need the query stream
+    assert L.bgsa_hip_select_scores(2, -3, -5) == 0
+    plain = L.bgsa_hip_workspace_bytes(B.ALGO_BITPAL, 150, 150, 100)
+    blocked_default = L.bgsa_hip_workspace_bytes(B.ALGO_BITPAL, 150, 1000, 100)
+    assert blocked_default > plain > 0
+    if (0, -1, -1) in B.score_sets():
+        assert L.bgsa_hip_select_scores(0, -1, -1) == 0
+        assert L.bgsa_hip_workspace_bytes(B.ALGO_BITPAL, 150, 150, 100) == plain
+        assert 0 < L.bgsa_hip_workspace_bytes(B.ALGO_BITPAL, 150, 1000, 100) < blocked_default   # 3 chains vs 13
+    assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0

@@ -306,3 +306,57 @@ def test_host_surface_matches_device_surface(oracle):
     group1 = peq[B.group_words(B.ALGO_MYERS, wn):]
     L.align_hip(row.ctypes.data, group1.ctypes.data, 150, length, wn, 1, 1, res.ctypes.data, None)
     assert np.array_equal(res[64:128], want[2, 64:128]) and not res[:64].any()
+
+
+# ---- BitPAl with other integer scores: every compiled set against the
+# Needleman-Wunsch oracle; the reference commits generator output for 2/-3/-5 only, so for the other
+# sets the DP definition is the checker -------------------------------------------------------------
+def _related(oracle, q, n, slen, seed):
+    s = oracle.gen_reads(seed, n, slen)
+    m = min(q.shape[1], slen)
+    rows = min(24, n)
+    s[:rows, :m] = oracle.mutate(q[np.arange(rows) % q.shape[0]][:, :m], np.arange(rows) * 3, seed + 1)
+    s[rows - 1, : m // 3] = ord("N")
+    return s
+
+
+@pytest.mark.parametrize("scores", B.score_sets() if B.LIB_PATH.exists() else [])
+@pytest.mark.parametrize("qlen,slen", [(150, 150), (1, 1), (40, 70), (97, 33), (250, 256), (31, 225), (150, 257),
+                                       (90, 300), (300, 600), (64, 513), (33, 1100)])
+def test_bitpal_score_sets_vs_needleman_wunsch(oracle, scores, qlen, slen):
+    q = oracle.gen_reads(100 + qlen, 5, qlen)
+    s = _related(oracle, q, 130, slen, 200 + slen)
+    got = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=scores)
+    assert np.array_equal(got, oracle.dp_nw(q, s, *scores))
+
+
+def test_bitpal_edit_scores_agree_with_the_myers_kernel(oracle):
+    if (0, -1, -1) not in B.score_sets():
+        pytest.skip("0/-1/-1 not compiled in")
+    q = oracle.gen_reads(5, 40, 150)
+    s = _related(oracle, q, 640, 150, 6)
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=(0, -1, -1)),
+                          B.align_all_pairs(q, s, algo=B.ALGO_MYERS))
+
+
+def test_score_sets_do_not_leak_between_aligners(oracle):
+    # the score set is process-global in the C ABI (the reference's ints): two aligners with
+    # different sets, used alternately, each keep their own
+    sets = [x for x in B.score_sets() if x != (2, -3, -5)]
+    if not sets:
+        pytest.skip("only the default set is compiled in")
+    q = oracle.gen_reads(21, 6, 120)
+    s = _related(oracle, q, 128, 120, 22)
+    a = B.DeviceAligner(B.ALGO_BITPAL)
+    b = B.DeviceAligner(B.ALGO_BITPAL, scores=sets[-1])
+    for x in (a, b):
+        x.set_queries(q)
+        x.set_subjects(s)
+    for _ in range(2):
+        assert np.array_equal(a.score().cpu().numpy(), oracle.bitpal(q, s))
+        assert np.array_equal(b.score().cpu().numpy(), oracle.dp_nw(q, s, *sets[-1]))
+
+
+def test_uncompiled_score_set_is_refused(oracle):
+    with pytest.raises(B.BgsaHipError, match="BITPAL_SETS"):
+        B.align_all_pairs(oracle.gen_reads(1, 2, 50), oracle.gen_reads(2, 64, 50), algo=B.ALGO_BITPAL, scores=(9, -9, -9))

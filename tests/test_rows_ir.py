@@ -179,3 +179,74 @@ def test_temp_allocation_is_consistent():
         body.simulate(st_a, eq)
         renamed.simulate(st_b, eq)
         assert all(np.array_equal(a, b) for a, b in zip(st_a, st_b))
+
+
+# ---- BitPAl for other integer scores: the generator's bodies against Needleman-Wunsch ----------------
+SCORE_SETS = [(2, -3, -5), (0, -1, -1), (1, -1, -1), (1, -1, -2), (1, -3, -2), (1, -2, -1), (3, -2, -4),
+              (5, -4, -10), (2, -6, -3), (1, -4, -2), (4, -1, -1), (1, -2, -1), (7, -1, -3)]
+
+
+def _related(oracle, q, n, slen, seed):
+    s = oracle.gen_reads(seed, n, slen)
+    m = min(q.shape[1], slen)
+    rows = min(24, n)
+    s[:rows, :m] = oracle.mutate(q[np.arange(rows) % q.shape[0]][:, :m], np.arange(rows), seed + 1)
+    s[rows - 1, : m // 3] = ord("N")
+    return s
+
+
+@pytest.mark.parametrize("scores", SCORE_SETS)
+@pytest.mark.parametrize("qlen,slen", [(150, 150), (40, 70), (97, 33)])
+def test_bitpal_any_scores_matches_needleman_wunsch(oracle, scores, qlen, slen):
+    sc = R.BitpalScores(*scores)
+    nw = (slen + 31) // 32
+    body = R.bitpal_body(nw, sc)
+    q = oracle.gen_reads(700 + qlen, 3, qlen)
+    s = _related(oracle, q, 64, slen, 800 + slen)
+    peq = R.build_peq32(s, nw)
+    want = oracle.dp_nw(q, s, *scores)
+    for i in range(q.shape[0]):
+        st = R.bitpal_init_state(nw, s.shape[0], sc)
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.bitpal_score(st, nw, qlen, slen, sc), want[i])
+
+
+@pytest.mark.parametrize("scores", [(0, -1, -1), (1, -3, -2), (5, -4, -10), (2, -6, -3)])
+@pytest.mark.parametrize("qlen,slen,nwb", [(70, 200, 3), (33, 97, 1), (64, 64, 1)])
+def test_bitpal_any_scores_column_blocks(oracle, scores, qlen, slen, nwb):
+    sc = R.BitpalScores(*scores)
+    q = oracle.gen_reads(900 + qlen, 2, qlen)
+    s = _related(oracle, q, 64, slen, 950 + slen)
+    want = oracle.dp_nw(q, s, *scores)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.bitpal_blocked_simulate(s, q[i], nwb, sc), want[i])
+
+
+def test_bitpal_default_scores_are_the_reference_instance():
+    # same planes, chains and instruction count as the body written after align_core.c:183-428
+    sc = R.BITPAL_DEFAULT
+    assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (5, 13, 12, 7, 5)
+    assert sc.weights() == (-1, -2, -4, -8, 16)
+    assert R.bitpal_body(1).valu_count() == 76
+
+
+def test_bitpal_edit_scores_equal_negated_myers(oracle):
+    q = oracle.gen_reads(11, 3, 100)
+    s = _related(oracle, q, 64, 100, 12)
+    assert np.array_equal(oracle.dp_nw(q, s, 0, -1, -1), oracle.myers64(q, s))
+
+
+@pytest.mark.parametrize("scores", [(1, 1, -1), (2, -7, -3), (2, -3, 0), (1, -1, 1)])
+def test_bitpal_rejects_score_sets_outside_the_method(scores):
+    with pytest.raises(ValueError):
+        R.BitpalScores(*scores)
+
+
+def test_bitpal_set_generator_picks_widths_that_fit(tmp_path):
+    import gen_rows_asm as G
+    for scores in [(2, -3, -5), (5, -4, -10), (0, -1, -1)]:
+        sc = R.BitpalScores(*scores)
+        plain, blocks = G.bitpal_widths(sc)
+        assert plain[0] == 1 and plain == list(range(1, plain[-1] + 1)) and blocks[-1] <= 8
+        assert sc.planes * plain[-1] + 5 * plain[-1] + R.bitpal_body(plain[-1], sc).allocate_temps()[1] <= G.BITPAL_VGPR_BUDGET
+    assert G.bitpal_widths(R.BITPAL_DEFAULT) == ([1, 2, 3, 4, 5, 6, 7, 8], [5, 6, 7, 8])
