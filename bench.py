@@ -61,7 +61,7 @@ def algorithmic_bytes_per_pair(algo: int, length: int, wn: int, q_tile: int = 10
     return out + peq / q_tile
 
 
-def issued_valu_per_row(algo: int, wn: int):
+def issued_valu_per_row(algo: int, wn: int, scores=None):
     """VALU instructions the shipped row body issues per (query row, wave), from the generator's
     own instruction lists (bgsa_amd/csrc/rows_ir.py); None for the compiler-scheduled kernels."""
     sys.path.insert(0, str(ROOT / "bgsa_amd" / "csrc"))
@@ -75,7 +75,7 @@ def issued_valu_per_row(algo: int, wn: int):
         nw = next(n for n in (12, 16, 20, 24, 28, 32) if n >= wn)
         return R.myers_planes_body(nw).valu_count()
     if algo == B.ALGO_BITPAL and wn <= 8:
-        return R.bitpal_body(wn).valu_count()
+        return R.bitpal_body(wn, R.BitpalScores(*scores) if scores else R.BITPAL_DEFAULT).valu_count()
     return None
 
 
@@ -142,6 +142,8 @@ def main() -> int:
     ap.add_argument("--nq", type=int, default=None, help="override query count (not the BASELINE config)")
     ap.add_argument("--ns", type=int, default=None, help="override subjects per GPU (not the BASELINE config)")
     ap.add_argument("--length", type=int, default=None, help="override read length (not the BASELINE config)")
+    ap.add_argument("--scores", type=str, default=None,
+                    help="match,mismatch,gap for config 4 (BitPAl); any set other than 2,-3,-5 is not a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="2000x100000", help="queries x subjects timed on the CPU")
     args = ap.parse_args()
@@ -163,7 +165,14 @@ def main() -> int:
         dist.init_process_group("nccl", device_id=dev)
 
     algo, cfg_name, nq, ns, length, k = CONFIGS[args.config]
-    overridden = args.nq is not None or args.ns is not None or args.length is not None
+    scores = tuple(int(x) for x in args.scores.split(",")) if args.scores else None
+    if scores is not None and algo != B.ALGO_BITPAL:
+        print("[bench] --scores only applies to --config 4", file=sys.stderr)
+        return 2
+    custom_scores = scores is not None and scores != (2, -3, -5)
+    overridden = args.nq is not None or args.ns is not None or args.length is not None or custom_scores
+    if custom_scores:
+        cfg_name = f"BitPAl packed M={scores[0]}/I={scores[1]}/G={scores[2]}, 10k x 1M, 150 bp"
     nq = args.nq or nq
     ns = args.ns or ns
     length = args.length or length
@@ -181,7 +190,7 @@ def main() -> int:
     s_rows[:, :length] = ord("N")  # padding reads, as the reference pads the last bucket (file.c:98-112)
     s_rows[:ns, :length] = letters[torch.randint(0, 4, (ns, length), generator=gen, device=dev)]
 
-    aligner = B.DeviceAligner(algo, f"cuda:{local_rank}", k)
+    aligner = B.DeviceAligner(algo, f"cuda:{local_rank}", k, scores if algo == B.ALGO_BITPAL else None)
     aligner.set_queries(q_rows.cpu().numpy())
     aligner.set_subject_rows_device(s_rows.reshape(-1), ns_pad, length, qlen=length)
     out = torch.empty((nq, ns_pad), dtype=aligner.out_dtype, device=dev)
@@ -251,7 +260,7 @@ def main() -> int:
         achieved_ops = kernel_gcups * 1e9 * ops_cell
         pairs_per_s = float(nq) * ns / kernel_s
         bpp = algorithmic_bytes_per_pair(algo, length, wn)
-        vpr = issued_valu_per_row(algo, wn)
+        vpr = issued_valu_per_row(algo, wn, scores)
         issued = None
         if vpr:
             issued_ops = vpr * 64.0 * (float(nq) * (ns_pad // 64) * length) / kernel_s
@@ -296,7 +305,7 @@ def main() -> int:
         }
         if gather_info:
             result["gather"] = gather_info
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not custom_scores:  # the reference commits 2/-3/-5 only
             cq, cs = (int(x) for x in args.cpu_sample.split("x"))
             cq, cs = min(cq, nq), min(cs, ns) // 8 * 8
             result["cpu_baseline"] = cpu_baseline(q_rows[:cq].cpu().numpy(), s_rows[:cs, :length].cpu().numpy(), algo, k)

@@ -6,7 +6,7 @@
  *
  *   ./aligner -q <query file> -d <database file> -f <result file> [-N host threads]
  *             [-k threshold] [-a myers|banded|bitpal] [-n gpus] [-g first gpu | g0,g1,...]
- *             [-R ratio file]
+ *             [-R ratio file] [-M match -I mismatch -G gap]
  *
  *   * input files: one sequence per line, all of one length (what `convert -f/-q` produces);
  *   * queries are mapped A,C,G,T,N -> 0..4 (file.c:117-140); the database is cut into read
@@ -150,6 +150,7 @@ static void usage(void)
     printf("  -N <arg>\n\t Number of host threads. \n\n");
     printf("  -k <arg>\n\t Filter threshold (banded). \n\n");
     printf("  -a <arg>\n\t Algorithm: myers (default), banded, bitpal. \n\n");
+    printf("  -M <arg> -I <arg> -G <arg>\n\t BitPAl match / mismatch / gap scores (a set the library was built with;\n\t default 2 / -3 / -5). Implies -a bitpal. \n\n");
     printf("  -n <arg>\n\t Number of GPUs. Default 1. \n\n");
     printf("  -g <arg>\n\t First GPU index, or a comma separated list of GPU indices. Default 0. \n\n");
     printf("  -R <arg>\n\t File with one work ratio per GPU (one number per line). Default: equal. \n\n");
@@ -229,8 +230,9 @@ int main(int argc, char **argv)
     const char *file_query = NULL, *file_database = NULL, *file_result = "result.txt";
     const char *gpu_list = "0", *file_ratio = NULL;
     int algo = BGSA_ALGO_MYERS, n_dev = 1, c;
+    int sc_match = 2, sc_mismatch = -3, sc_gap = -5, sc_given = 0; /* the generator's -M -I -G (README.md:58-66) */
     threshold = HIP_BANDED_WORD_SIZE / 2 - 1; /* banded/BGSA_CPU/main.c:43 */
-    while ((c = getopt(argc, argv, "t:q:d:f:n:N:M:k:a:g:R:Dh")) != -1) {
+    while ((c = getopt(argc, argv, "t:q:d:f:n:N:M:I:G:k:a:g:R:Dh")) != -1) {
         switch (c) {
         case 'q': file_query = optarg; break;
         case 'd': file_database = optarg; break;
@@ -246,7 +248,10 @@ int main(int argc, char **argv)
             else if (!strcmp(optarg, "bitpal")) algo = BGSA_ALGO_BITPAL;
             else usage();
             break;
-        case 't': case 'M': case 'D': break; /* KNC-only knobs: accepted, ignored */
+        case 'M': sc_match = atoi(optarg); sc_given = 1; break;
+        case 'I': sc_mismatch = atoi(optarg); sc_given = 1; break;
+        case 'G': sc_gap = atoi(optarg); sc_given = 1; break;
+        case 't': case 'D': break; /* KNC-only knobs: accepted, ignored */
         default: usage();
         }
     }
@@ -287,7 +292,9 @@ int main(int argc, char **argv)
     }
 
     double total_start = now(), mem_time = 0, cal_time = 0;
+    if (sc_given) algo = BGSA_ALGO_BITPAL;
     CK(bgsa_hip_select_algorithm(algo));
+    if (sc_given) CK(bgsa_hip_select_scores(sc_match, sc_mismatch, sc_gap));
     init_mapping_table();
     const size_t esz = algo == BGSA_ALGO_BANDED ? sizeof(hip_banded_write_t) : sizeof(hip_write_t);
 

@@ -124,3 +124,26 @@ def test_cli_rejects_missing_gpu(tmp_path):
     p = subprocess.run([str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-g", "63"],
                        cwd=tmp_path, capture_output=True, text=True)
     assert p.returncode != 0 and "does not exist" in p.stdout
+
+
+def test_cli_bitpal_with_other_scores(tmp_path, oracle):
+    sets = [x for x in B.score_sets() if x != (2, -3, -5)]
+    if not sets:
+        pytest.skip("only the default score set is compiled in")
+    m, x, g_ = sets[-1]
+    q = oracle.gen_reads(97, 9, 150)
+    s = oracle.gen_reads(98, 200, 150)
+    s[:9] = oracle.mutate(q, np.arange(9) * 2, 99)
+    g = {"queries": q, "subjects": s, "variant": "original_avx2", "k": -1}
+    got, report = _run_cli(tmp_path, g, extra_args=["-M", str(m), "-I", str(x), "-G", str(g_)])
+    assert np.array_equal(got, oracle.dp_nw(q, s, m, x, g_))
+    assert f"score is {m}, {x}, {g_}" in report
+
+
+def test_cli_refuses_uncompiled_scores(tmp_path):
+    g = load_golden("f1_myers_150")
+    (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
+    (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
+    p = subprocess.run([str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-M", "9", "-I", "-9", "-G", "-9"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert p.returncode != 0 and "BITPAL_SETS" in p.stdout

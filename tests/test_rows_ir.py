@@ -227,7 +227,7 @@ def test_bitpal_default_scores_are_the_reference_instance():
     sc = R.BITPAL_DEFAULT
     assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (5, 13, 12, 7, 5)
     assert sc.weights() == (-1, -2, -4, -8, 16)
-    assert R.bitpal_body(1).valu_count() == 76
+    assert R.bitpal_body(1).valu_count() == 75
 
 
 def test_bitpal_edit_scores_equal_negated_myers(oracle):
