@@ -62,6 +62,7 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_last_error.restype = ctypes.c_char_p
     L.bgsa_hip_select_algorithm.argtypes = [i32]
     L.bgsa_hip_select_scores.argtypes = [i32, i32, i32]
+    L.bgsa_hip_select_alignment.argtypes = [i32]
     ip = ctypes.POINTER(i32)
     L.bgsa_hip_score_set.argtypes = [i32, ip, ip, ip, ip]
     L.bgsa_hip_word_num.argtypes = [i32, i32, i32, i32]
@@ -163,14 +164,17 @@ class DeviceAligner:
     252-401): preprocess the bucket once, then loop over query buckets calling the grid.
     """
 
-    def __init__(self, algo: int = ALGO_MYERS, device: str = "cuda:0", k: int = 0, scores=None):
-        """scores: (match, mismatch, gap) for ALGO_BITPAL; None = the reference's 2 / -3 / -5."""
+    def __init__(self, algo: int = ALGO_MYERS, device: str = "cuda:0", k: int = 0, scores=None,
+                 semi_global: bool = False):
+        """scores: (match, mismatch, gap) for ALGO_BITPAL; None = the reference's 2 / -3 / -5.
+        semi_global: ALGO_BITPAL only — query end to end, free subject overhangs (generator -s)."""
         import torch
         self.torch = torch
         self.algo, self.k = algo, int(k)
         self.scores = tuple(int(x) for x in scores) if scores is not None else None
-        if self.scores is not None and algo != ALGO_BITPAL:
-            raise BgsaHipError("scores only apply to ALGO_BITPAL")
+        self.semi_global = bool(semi_global)
+        if (self.scores is not None or self.semi_global) and algo != ALGO_BITPAL:
+            raise BgsaHipError("scores / semi_global only apply to ALGO_BITPAL")
         self.device = torch.device(device)
         if not torch.cuda.is_available():
             raise BgsaHipError("no GPU visible: the HIP path has no CPU fallback")
@@ -231,9 +235,10 @@ class DeviceAligner:
         return out
 
     def _select(self) -> None:
-        # the score set is process-global state of the C ABI (the reference's three ints)
+        # the score set and the alignment mode are process-global state of the C ABI (the reference's ints)
         if self.algo == ALGO_BITPAL:
             check(lib().bgsa_hip_select_scores(*(self.scores or (2, -3, -5))), "select_scores")
+        check(lib().bgsa_hip_select_alignment(1 if self.semi_global else 0), "select_alignment")
 
     def kernel_name(self) -> str:
         self._select()
@@ -241,9 +246,9 @@ class DeviceAligner:
 
 
 def align_all_pairs(queries: np.ndarray, subjects: np.ndarray, algo: int = ALGO_MYERS, k: int = 0,
-                    device: str = "cuda:0", scores=None) -> np.ndarray:
+                    device: str = "cuda:0", scores=None, semi_global: bool = False) -> np.ndarray:
     """Convenience: scores[nq, ns] for small inputs, through the device-resident C ABI."""
-    a = DeviceAligner(algo, device, k, scores)
+    a = DeviceAligner(algo, device, k, scores, semi_global)
     a.set_queries(queries)
     a.set_subjects(subjects)
     out = a.score()

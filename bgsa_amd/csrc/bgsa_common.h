@@ -158,7 +158,7 @@ struct BitpalSet {
     int valu_per_word;
     int (*launch)(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
                   int64_t read_count, int ref_start, int ref_end, int word_num, void *d_workspace,
-                  hipStream_t stream);
+                  hipStream_t stream, int semi_global);
     const char *(*kernel_name)(int word_num);
 };
 int bitpal_set_count();
@@ -169,7 +169,7 @@ const BitpalSet *bitpal_current_set();  // the set of the ABI's score globals; n
 // Scores with the set selected by the ABI's match_score / mismatch_score / gap_score.
 int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                  void *d_workspace, hipStream_t stream);
+                  void *d_workspace, hipStream_t stream, int semi_global);
 const char *bitpal_kernel_name(int word_num);
 
 // long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.

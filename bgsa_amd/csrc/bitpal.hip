@@ -65,16 +65,16 @@ const char *bitpal_kernel_name(int word_num)
 
 int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                  void *d_workspace, hipStream_t stream)
+                  void *d_workspace, hipStream_t stream, int semi_global)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
     const BitpalSet *s = bitpal_current_set();
     if (!s) return BGSA_HIP_EUNSUPPORTED;
-    if (word_num > s->max_plain && bitpal_c_impl(s))  // A/B: the state-in-memory C++ kernel
+    if (word_num > s->max_plain && bitpal_c_impl(s) && !semi_global)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);
     return s->launch(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
-                     d_workspace, stream);
+                     d_workspace, stream, semi_global);
 }
 
 }  // namespace bgsa

@@ -27,12 +27,41 @@ __device__ __forceinline__ int bitpal_column_sum(const uint32_t *st, int first_w
     return sum;
 }
 
+// Semi-global (generator option -s, BitPAlGenerator.java:78-116): walk the last DP row one subject
+// column at a time, run = S[m][j], best = the maximum so far.  Once per (query, subject) pair — about
+// 3 % of the row loop's work at 150 bp.
 template <int NW>
+__device__ __forceinline__ void bitpal_last_row_max(const uint32_t *st, int first_word, int read_len, int &run, int &best)
+{
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        int cols = read_len - 32 * (first_word + w);
+        cols = cols > 32 ? 32 : cols;
+        for (int j = 0; j < cols; j++) {   // cols is wave-uniform
+            int u = 0;
+#pragma unroll
+            for (int i = 0; i < kBitpalPlanes; i++) u += kBitpalWeights[i] * static_cast<int>((st[w * kBitpalPlanes + i] >> j) & 1u);
+            run += u + kBitpalGap;
+            best = run > best ? run : best;
+        }
+    }
+}
+
+// Row 0 of the DP: dH = gap everywhere (global: stored -u = 0) or dH = 0 (semi-global: u = -gap,
+// writeBitInitStr, BitPAlGenerator.java:2201-2218).
+__device__ __forceinline__ uint32_t bitpal_init_plane(int plane, int semi)
+{
+    constexpr uint32_t stored = static_cast<uint32_t>(kBitpalGap) & ((1u << kBitpalPlanes) - 1u);
+    return (semi && ((stored >> plane) & 1u)) ? ~0u : 0u;
+}
+
+template <int NW, bool SEMI>
 __global__ __launch_bounds__(256) void bitpal_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
     int n_queries, int q_tile, int stream_stride_bytes)
 {
+    constexpr int semi = SEMI;
     const int lane = threadIdx.x & (kLanes - 1);
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (group >= n_groups) return;
@@ -52,11 +81,18 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
     for (int q = q0; q < q1; q++) {
         uint32_t st[kBitpalPlanes * NW];
 #pragma unroll
-        for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = 0u;  // every column starts at dH = gap (:167-171)
+        for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);  // (:167-171)
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
         bitpal_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
-        const int score = kBitpalGap * (ref_len + read_len) + bitpal_column_sum<NW>(st, 0, read_len);
+        int score;
+        if (semi) {
+            int run = kBitpalGap * ref_len;
+            score = run;
+            bitpal_last_row_max<NW>(st, 0, read_len, run, score);
+        } else {
+            score = kBitpalGap * (ref_len + read_len) + bitpal_column_sum<NW>(st, 0, read_len);
+        }
         dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(score);
     }
 }
@@ -64,12 +100,13 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
 // Subjects wider than kBitpalMaxPlain words: column blocks of NW words, the carry chains of a row
 // crossing block boundaries through per-wave carry words (same scheme as myers_blocked_kernel;
 // rows_ir.py: make_blocked, CPU-simulated in tests/test_rows_ir.py).
-template <int NW>
+template <int NW, bool SEMI>
 __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
     int n_queries, int q_tile, int stream_stride_bytes, int n_blocks)
 {
+    constexpr int semi = SEMI;
     constexpr int NC = kBitpalChains;
     constexpr int NS = kBitpalPlanes * NW;
     const int lane = threadIdx.x & (kLanes - 1);
@@ -92,7 +129,8 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
             for (int i = 0; i < n_chunks * NC; i++) carry[i * kLanes + lane] = 0u;  // every chain starts at carry-in 0
             const unsigned long long s =
                 reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-            int score = kBitpalGap * (ref_len + read_len);
+            int score = semi ? kBitpalGap * ref_len : kBitpalGap * (ref_len + read_len);
+            int run = score;  // semi-global: S[m][j] walking right along the last row; score = its maximum
             for (int blk = 0; blk < n_blocks; blk++) {
                 uint32_t P[kChars][NW];
 #pragma unroll
@@ -104,7 +142,7 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
                     }
                 uint32_t st[NS + 2 * NC];
 #pragma unroll
-                for (int i = 0; i < NS; i++) st[i] = 0u;
+                for (int i = 0; i < NS; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);
 #pragma unroll
                 for (int i = 0; i < NC; i++) {
                     st[NS + i] = carry[i * kLanes + lane];  // chunk 0
@@ -118,7 +156,10 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
                     const uint32_t word = tail_rows ? (st[NS + NC + i] << (32 - tail_rows)) : st[NS + NC + i];
                     carry[((n_chunks - 1) * NC + i) * kLanes + lane] = word;
                 }
-                score += bitpal_column_sum<NW>(st, blk * NW, read_len);
+                if (semi)
+                    bitpal_last_row_max<NW>(st, blk * NW, read_len, run, score);
+                else
+                    score += bitpal_column_sum<NW>(st, blk * NW, read_len);
             }
             out[static_cast<size_t>(q) * ld + static_cast<size_t>(group) * kLanes + lane] = static_cast<int16_t>(score);
         }
@@ -140,14 +181,15 @@ inline int pick_block_nw(int word_num, int *n_blocks)
 template <int NW>
 int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
                    int64_t read_count, int ref_start, int ref_end, int word_num, int n_blocks, void *d_workspace,
-                   hipStream_t stream)
+                   hipStream_t stream, int semi)
 {
     const int nq = ref_end - ref_start;
     const int stride = blocked_stream_layout(ref_len, nullptr, nullptr);
     const size_t stream_bytes = (static_cast<size_t>(stride) * nq + 255) & ~static_cast<size_t>(255);
     if (int rc = launch_pack_blocked(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
     uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
-    hipLaunchKernelGGL((bitpal_blocked_kernel<NW>), dim3(kBlockedBlocks), dim3(256), 0, stream,
+    auto kernel = semi ? bitpal_blocked_kernel<NW, true> : bitpal_blocked_kernel<NW, false>;
+    hipLaunchKernelGGL(kernel, dim3(kBlockedBlocks), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
                        stride, n_blocks);
@@ -165,7 +207,7 @@ inline int pick_q_tile(int nq, int64_t n_groups)
 template <int NW>
 int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
               int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-              void *d_workspace, hipStream_t stream)
+              void *d_workspace, hipStream_t stream, int semi)
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
@@ -177,7 +219,8 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
         return BGSA_HIP_EUNSUPPORTED;
     }
     if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
-    hipLaunchKernelGGL(bitpal_asm_kernel<NW>, grid, dim3(256), 0, stream,
+    auto kernel = semi ? bitpal_asm_kernel<NW, true> : bitpal_asm_kernel<NW, false>;
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
                        nq, q_tile, static_cast<int>(stream_stride(ref_len)));
@@ -201,7 +244,7 @@ const char *set_kernel_name(int word_num)
 
 int set_launch(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-               void *d_workspace, hipStream_t stream)
+               void *d_workspace, hipStream_t stream, int semi)
 {
     if (word_num > kBitpalMaxPlain) {
         int n_blocks = 0;
@@ -209,7 +252,7 @@ int set_launch(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
 #define X(N)                                                                                     \
     case N:                                                                                      \
         return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
-                                 ref_end, word_num, n_blocks, d_workspace, stream);
+                                 ref_end, word_num, n_blocks, d_workspace, stream, semi);
             BGSA_BITPAL_BLOCK_WIDTHS(X)
 #undef X
         default: break;
@@ -219,7 +262,7 @@ int set_launch(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
 #define X(N)                                                                                    \
     case N:                                                                                     \
         return launch_nw<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,         \
-                            ref_start, ref_end, word_num, d_workspace, stream);
+                            ref_start, ref_end, word_num, d_workspace, stream, semi);
         BGSA_BITPAL_PLAIN_WIDTHS(X)
 #undef X
     default:

@@ -30,6 +30,7 @@ void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint3
                        int word_num, int64_t read_count, int k, int threads);
 
 static int g_algo = BGSA_ALGO_MYERS;
+static int g_alignment = BGSA_ALIGN_GLOBAL;
 
 // Grow-only device workspace behind the host-buffer entry points.
 struct HostPathWorkspace {
@@ -112,6 +113,17 @@ int bgsa_hip_select_algorithm(int algo)
     return BGSA_HIP_OK;
 }
 int bgsa_hip_current_algorithm(void) { return g_algo; }
+
+int bgsa_hip_select_alignment(int mode)
+{
+    if (mode != BGSA_ALIGN_GLOBAL && mode != BGSA_ALIGN_SEMIGLOBAL) {
+        set_error_text("select_alignment: unknown mode");
+        return BGSA_HIP_EINVAL;
+    }
+    g_alignment = mode;
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_current_alignment(void) { return g_alignment; }
 
 int bgsa_hip_select_scores(int match, int mismatch, int gap)
 {
@@ -296,6 +308,10 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         set_error_text("cal_align_score_dev: bad argument (read_count must be a multiple of 64)");
         return BGSA_HIP_EINVAL;
     }
+    if (g_alignment == BGSA_ALIGN_SEMIGLOBAL && algo != BGSA_ALGO_BITPAL) {
+        set_error_text("cal_align_score_dev: semi-global alignment is implemented for BGSA_ALGO_BITPAL only");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t need = bgsa_hip_workspace_bytes(algo, ref_len, read_len, ref_end - ref_start);
     if (d_workspace) {
@@ -324,7 +340,8 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
             return BGSA_HIP_EINVAL;
         }
         return launch_bitpal(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len,
-                             read_len, read_count, ref_start, ref_end, word_num, d_workspace, s);
+                             read_len, read_count, ref_start, ref_end, word_num, d_workspace, s,
+                             g_alignment == BGSA_ALIGN_SEMIGLOBAL);
     default:
         set_error_text("cal_align_score_dev: unknown algorithm");
         return BGSA_HIP_EINVAL;

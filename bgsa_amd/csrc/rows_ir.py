@@ -862,14 +862,35 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     return b
 
 
-def bitpal_scores_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT) -> list:
-    return [np.zeros(lanes, dtype=np.uint32) for _ in range(sc.planes * nw)]   # every column at dH = G
+def bitpal_scores_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT, semi: bool = False) -> list:
+    """Row 0: every column at dH = G (global), or at dH = 0, i.e. u = -G (semi-global: the
+    generator's writeBitInitStr, BitPAlGenerator.java:2201-2218)."""
+    stored = (sc.gap & ((1 << sc.planes) - 1)) if semi else 0       # two's complement of -u
+    return [np.full(lanes, 0xFFFFFFFF if (stored >> i) & 1 else 0, dtype=np.uint32)
+            for _ in range(nw) for i in range(sc.planes)]
 
 
-def bitpal_scores_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalScores = BITPAL_DEFAULT) -> np.ndarray:
-    """S[m][n] = G*(m + n) + sum over subject columns of u."""
-    score = np.full(state[0].shape, sc.gap * (qlen + slen), dtype=np.int64)
+def bitpal_column_values(state: list, w: int, sc: BitpalScores) -> np.ndarray:
+    """u of the 32 columns of word w: [lanes, 32] int64."""
     B = sc.planes
+    bits = np.arange(32, dtype=np.uint32)
+    u = np.zeros((state[0].shape[0], 32), dtype=np.int64)
+    for i, wt in enumerate(sc.weights()):
+        u += wt * ((state[w * B + i][:, None] >> bits[None, :]) & np.uint32(1)).astype(np.int64)
+    return u
+
+
+def bitpal_scores_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalScores = BITPAL_DEFAULT,
+                        semi: bool = False) -> np.ndarray:
+    """Global: S[m][n] = G*(m + n) + sum over subject columns of u.  Semi-global: the maximum of
+    S[m][j] = G*m + sum_{c <= j} (u_c + G) over j = 0..n (genPackedScore, BitPAlGenerator.java:78-116)."""
+    B = sc.planes
+    if semi:
+        u = np.concatenate([bitpal_column_values(state, w, sc) for w in range(nw)], axis=1)[:, :slen]
+        run = sc.gap * qlen + np.cumsum(u + sc.gap, axis=1)
+        best = np.maximum(run.max(axis=1, initial=-(1 << 40)), sc.gap * qlen)
+        return best.astype(np.int16)
+    score = np.full(state[0].shape, sc.gap * (qlen + slen), dtype=np.int64)
     for w in range(nw):
         rem = slen - 32 * w
         mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
@@ -918,16 +939,17 @@ def bitpal_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     return bitpal_scores_body(nw, sc)
 
 
-def bitpal_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT) -> list:
-    return bitpal_scores_init_state(nw, lanes, sc)
+def bitpal_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT, semi: bool = False) -> list:
+    return bitpal_scores_init_state(nw, lanes, sc, semi)
 
 
-def bitpal_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalScores = BITPAL_DEFAULT) -> np.ndarray:
-    return bitpal_scores_score(state, nw, qlen, slen, sc)
+def bitpal_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalScores = BITPAL_DEFAULT,
+                 semi: bool = False) -> np.ndarray:
+    return bitpal_scores_score(state, nw, qlen, slen, sc, semi)
 
 
 def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int,
-                            sc: BitpalScores = BITPAL_DEFAULT) -> np.ndarray:
+                            sc: BitpalScores = BITPAL_DEFAULT, semi: bool = False) -> np.ndarray:
     """BitPAl over column blocks of nw_block words with carry words between blocks — the scheme of
     bitpal_blocked_kernel at toy scale.  Returns int16."""
     n, slen = subjects.shape
@@ -942,11 +964,11 @@ def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: i
     code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
     n_chunks = (qlen + 31) // 32
     carry = [[np.zeros(n, np.uint32) for k in range(n_ch)] for _ in range(n_chunks)]
-    score = np.full(n, sc.gap * (qlen + slen), dtype=np.int64)
-    weights = sc.weights()
+    run = np.full(n, sc.gap * qlen, dtype=np.int64)      # S[m][j] walking right along the last row
+    best = run.copy()
     base = B * nw_block
     for blk in range(n_blocks):
-        st = [np.zeros(n, np.uint32) for _ in range(base)] + [c.copy() for c in carry[0]] + \
+        st = bitpal_init_state(nw_block, n, sc, semi) + [c.copy() for c in carry[0]] + \
              [np.zeros(n, np.uint32) for _ in range(n_ch)]
         for r, ch in enumerate(query):
             if r > 0 and r % 32 == 0:
@@ -962,11 +984,13 @@ def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: i
             last = [x << np.uint32(32 - tail) for x in last]
         carry[n_chunks - 1] = [x.copy() for x in last]
         for w in range(nw_block):
-            rem = slen - 32 * (blk * nw_block + w)
-            mask = np.uint32(0xFFFFFFFF if rem >= 32 else (0 if rem <= 0 else (1 << rem) - 1))
-            for i, wt in enumerate(weights):
-                score += wt * np.bitwise_count(st[w * B + i] & mask).astype(np.int64)
-    return score.astype(np.int16)
+            cols = min(32, max(0, slen - 32 * (blk * nw_block + w)))
+            if cols == 0:
+                continue
+            steps = run[:, None] + np.cumsum(bitpal_column_values(st, w, sc)[:, :cols] + sc.gap, axis=1)
+            best = np.maximum(best, steps.max(axis=1))
+            run = steps[:, -1]
+    return (best if semi else run).astype(np.int16)
 
 
 # =================================================================================================

@@ -6,7 +6,7 @@
  *
  *   ./aligner -q <query file> -d <database file> -f <result file> [-N host threads]
  *             [-k threshold] [-a myers|banded|bitpal] [-n gpus] [-g first gpu | g0,g1,...]
- *             [-R ratio file] [-M match -I mismatch -G gap]
+ *             [-R ratio file] [-M match -I mismatch -G gap] [-s]
  *
  *   * input files: one sequence per line, all of one length (what `convert -f/-q` produces);
  *   * queries are mapped A,C,G,T,N -> 0..4 (file.c:117-140); the database is cut into read
@@ -151,6 +151,7 @@ static void usage(void)
     printf("  -k <arg>\n\t Filter threshold (banded). \n\n");
     printf("  -a <arg>\n\t Algorithm: myers (default), banded, bitpal. \n\n");
     printf("  -M <arg> -I <arg> -G <arg>\n\t BitPAl match / mismatch / gap scores (a set the library was built with;\n\t default 2 / -3 / -5). Implies -a bitpal. \n\n");
+    printf("  -s\n\t Semi-global BitPAl: query end to end, free subject overhangs (implies -a bitpal). \n\n");
     printf("  -n <arg>\n\t Number of GPUs. Default 1. \n\n");
     printf("  -g <arg>\n\t First GPU index, or a comma separated list of GPU indices. Default 0. \n\n");
     printf("  -R <arg>\n\t File with one work ratio per GPU (one number per line). Default: equal. \n\n");
@@ -231,8 +232,9 @@ int main(int argc, char **argv)
     const char *gpu_list = "0", *file_ratio = NULL;
     int algo = BGSA_ALGO_MYERS, n_dev = 1, c;
     int sc_match = 2, sc_mismatch = -3, sc_gap = -5, sc_given = 0; /* the generator's -M -I -G (README.md:58-66) */
+    int semi = 0;                                                   /* the generator's -s */
     threshold = HIP_BANDED_WORD_SIZE / 2 - 1; /* banded/BGSA_CPU/main.c:43 */
-    while ((c = getopt(argc, argv, "t:q:d:f:n:N:M:I:G:k:a:g:R:Dh")) != -1) {
+    while ((c = getopt(argc, argv, "t:q:d:f:n:N:M:I:G:k:a:g:R:Dsh")) != -1) {
         switch (c) {
         case 'q': file_query = optarg; break;
         case 'd': file_database = optarg; break;
@@ -251,6 +253,7 @@ int main(int argc, char **argv)
         case 'M': sc_match = atoi(optarg); sc_given = 1; break;
         case 'I': sc_mismatch = atoi(optarg); sc_given = 1; break;
         case 'G': sc_gap = atoi(optarg); sc_given = 1; break;
+        case 's': semi = 1; break;
         case 't': case 'D': break; /* KNC-only knobs: accepted, ignored */
         default: usage();
         }
@@ -292,9 +295,10 @@ int main(int argc, char **argv)
     }
 
     double total_start = now(), mem_time = 0, cal_time = 0;
-    if (sc_given) algo = BGSA_ALGO_BITPAL;
+    if (sc_given || semi) algo = BGSA_ALGO_BITPAL;
     CK(bgsa_hip_select_algorithm(algo));
     if (sc_given) CK(bgsa_hip_select_scores(sc_match, sc_mismatch, sc_gap));
+    CK(bgsa_hip_select_alignment(semi ? BGSA_ALIGN_SEMIGLOBAL : BGSA_ALIGN_GLOBAL));
     init_mapping_table();
     const size_t esz = algo == BGSA_ALGO_BANDED ? sizeof(hip_banded_write_t) : sizeof(hip_write_t);
 

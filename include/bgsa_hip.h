@@ -97,6 +97,15 @@ int bgsa_hip_current_algorithm(void);
  * (index 0 = the reference's committed 2/-3/-5); valu_per_word = VALU instructions per (row, 32
  * columns) of that set's kernel.  Any out-pointer may be NULL. */
 int bgsa_hip_select_scores(int match, int mismatch, int gap);
+
+/* Global (default) or semi-global scoring — the generator's `-s` option (Configuration.isSemiGlobal;
+ * BitPAlGenerator.java:2201-2218 first row, :78-116 last-row maximum): the query is aligned end to
+ * end, subject overhangs before and after it are free, result = max over the last DP row.
+ * Implemented for BGSA_ALGO_BITPAL (any compiled score set); scoring another algorithm while
+ * semi-global is selected returns BGSA_HIP_EUNSUPPORTED.  Process-global like the score ints. */
+enum { BGSA_ALIGN_GLOBAL = 0, BGSA_ALIGN_SEMIGLOBAL = 1 };
+int bgsa_hip_select_alignment(int mode);
+int bgsa_hip_current_alignment(void);
 int bgsa_hip_score_set_count(void);
 int bgsa_hip_score_set(int index, int *match, int *mismatch, int *gap, int *valu_per_word);
 

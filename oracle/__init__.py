@@ -54,6 +54,8 @@ def lib() -> ctypes.CDLL:
         L.bgsa_oracle_dp_banded.restype = None
         L.bgsa_oracle_dp_nw.argtypes = common + [i32, i32, i32, c_p, i32]
         L.bgsa_oracle_dp_nw.restype = None
+        L.bgsa_oracle_dp_semiglobal.argtypes = common + [i32, i32, i32, c_p, i32]
+        L.bgsa_oracle_dp_semiglobal.restype = None
         L.bgsa_oracle_myers_avx2.argtypes = common + [c_p, i32]
         L.bgsa_oracle_myers_avx2.restype = ctypes.c_double
         _lib = L
@@ -111,6 +113,11 @@ def dp_edit(q, s, threads=0):
 
 def dp_nw(q, s, match=2, mismatch=-3, gap=-5, threads=0):
     return _run("dp_nw", q, s, np.int16, extra=(match, mismatch, gap), threads=threads)[0]
+
+
+def dp_semiglobal(q, s, match=2, mismatch=-3, gap=-5, threads=0):
+    """Query end to end, free subject overhangs: max over the last DP row (generator option -s)."""
+    return _run("dp_semiglobal", q, s, np.int16, extra=(match, mismatch, gap), threads=threads)[0]
 
 
 def dp_banded(q, s, k, threads=0):

@@ -574,6 +574,52 @@ void bgsa_oracle_dp_nw(const char *queries, int64_t nq, int qlen, const char *su
 }
 
 /*
+ * Semi-global DP as the reference's generator defines it for BitPAl (`-s`, generator/source/.../
+ * BitPAlGenerator.java: writeBitInitStr :2201-2218 makes every dH of row 0 zero, genPackedScore
+ * :78-116 starts at gap*query_len and keeps the maximum while it walks the last row): the query is
+ * aligned end to end, subject overhangs on both sides are free.
+ *   S[0][j] = 0,  S[i][0] = i*gap,  result = max over j in [0, slen] of S[qlen][j].
+ * No committed reference output exists for this mode (generator option only): the DP definition is
+ * the checker.
+ */
+void bgsa_oracle_dp_semiglobal(const char *queries, int64_t nq, int qlen, const char *subjects,
+                               int64_t ns, int slen, int match, int mismatch, int gap, int16_t *out,
+                               int threads)
+{
+    if (nq <= 0 || ns <= 0) return;
+    uint8_t *q = map_rows(queries, nq, qlen);
+    uint8_t *s = map_rows(subjects, ns, slen);
+#pragma omp parallel num_threads(pick_threads(threads))
+    {
+        int *row = (int *)malloc(sizeof(int) * (size_t)(slen + 1));
+#pragma omp for schedule(dynamic, 16) collapse(2)
+        for (int64_t i = 0; i < nq; i++)
+            for (int64_t j = 0; j < ns; j++) {
+                const uint8_t *a = q + i * qlen, *b = s + j * slen;
+                for (int x = 0; x <= slen; x++) row[x] = 0;
+                for (int y = 1; y <= qlen; y++) {
+                    int diag = row[0];
+                    row[0] = y * gap;
+                    for (int x = 1; x <= slen; x++) {
+                        int up = row[x];
+                        int best = diag + (a[y - 1] == b[x - 1] ? match : mismatch);
+                        if (up + gap > best) best = up + gap;
+                        if (row[x - 1] + gap > best) best = row[x - 1] + gap;
+                        row[x] = best;
+                        diag = up;
+                    }
+                }
+                int best = row[0];
+                for (int x = 1; x <= slen; x++)
+                    if (row[x] > best) best = row[x];
+                out[i * ns + j] = (int16_t)best;
+            }
+        free(row);
+    }
+    free(q); free(s);
+}
+
+/*
  * Closed form of the banded kernel (validated there against the compiled
  * reference for qlen == slen): unit-cost DP with D[i][0] = i, D[0][j] = 0, cells restricted to
  * diagonals j - i in [-(k+1), h]; 127 if D[m-k][m-2k-1] > k+h+1; else min over j in [m-k-1, n]

@@ -73,6 +73,11 @@ void bgsa_oracle_dp_nw(const char *queries, int64_t nq, int qlen,
                        const char *subjects, int64_t ns, int slen,
                        int match, int mismatch, int gap,
                        int16_t *out, int threads);
+/* S[0][j] = 0, S[i][0] = i*gap, result = max over the last row (the generator's -s mode for BitPAl). */
+void bgsa_oracle_dp_semiglobal(const char *queries, int64_t nq, int qlen,
+                       const char *subjects, int64_t ns, int slen,
+                       int match, int mismatch, int gap,
+                       int16_t *out, int threads);
 /* Closed form of the banded kernel's output for qlen == slen. */
 void bgsa_oracle_dp_banded(const char *queries, int64_t nq, int qlen,
                            const char *subjects, int64_t ns, int slen,

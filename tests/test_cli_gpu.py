@@ -147,3 +147,14 @@ def test_cli_refuses_uncompiled_scores(tmp_path):
     p = subprocess.run([str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-M", "9", "-I", "-9", "-G", "-9"],
                        cwd=tmp_path, capture_output=True, text=True)
     assert p.returncode != 0 and "BITPAL_SETS" in p.stdout
+
+
+def test_cli_semiglobal(tmp_path, oracle):
+    q = oracle.gen_reads(61, 5, 60)
+    s = oracle.gen_reads(62, 100, 150)
+    for r in range(10):
+        s[r, 9 * r: 9 * r + 60] = q[r % 5]
+    g = {"queries": q, "subjects": s, "variant": "original_avx2", "k": -1}
+    got, _ = _run_cli(tmp_path, g, extra_args=["-s"])
+    assert np.array_equal(got, oracle.dp_semiglobal(q, s))
+    assert (got[np.arange(10) % 5, np.arange(10)] == 120).all()     # exact copies: 60 matches x 2

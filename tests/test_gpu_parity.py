@@ -360,3 +360,39 @@ def test_score_sets_do_not_leak_between_aligners(oracle):
 def test_uncompiled_score_set_is_refused(oracle):
     with pytest.raises(B.BgsaHipError, match="BITPAL_SETS"):
         B.align_all_pairs(oracle.gen_reads(1, 2, 50), oracle.gen_reads(2, 64, 50), algo=B.ALGO_BITPAL, scores=(9, -9, -9))
+
+
+# ---- semi-global BitPAl (generator option -s): DP definition as the checker ------------------------------
+@pytest.mark.parametrize("scores", B.score_sets() if B.LIB_PATH.exists() else [])
+@pytest.mark.parametrize("qlen,slen", [(60, 150), (150, 150), (97, 33), (1, 1), (20, 256), (100, 300), (50, 1000), (300, 777)])
+def test_bitpal_semiglobal_vs_dp(oracle, scores, qlen, slen):
+    q = oracle.gen_reads(300 + qlen, 4, qlen)
+    s = oracle.gen_reads(400 + slen, 130, slen)
+    if slen >= qlen:
+        for r in range(24):   # the query, lightly edited, somewhere inside the subject
+            off = (r * 13) % (slen - qlen + 1)
+            s[r, off:off + qlen] = oracle.mutate(q[r % 4: r % 4 + 1], [r % 6], 500 + r)[0]
+    got = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=scores, semi_global=True)
+    assert np.array_equal(got, oracle.dp_semiglobal(q, s, *scores))
+
+
+def test_semiglobal_is_refused_for_other_algorithms_and_does_not_stick(oracle):
+    q, s = oracle.gen_reads(1, 3, 80), oracle.gen_reads(2, 64, 80)
+    with pytest.raises(B.BgsaHipError):
+        B.DeviceAligner(B.ALGO_MYERS, semi_global=True)
+    semi = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, semi_global=True)
+    assert np.array_equal(semi, oracle.dp_semiglobal(q, s))
+    # the mode is process-global in the C ABI; the next aligner sets its own
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL), oracle.bitpal(q, s))
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), oracle.myers64(q, s))
+    L = B.lib()
+    assert L.bgsa_hip_select_alignment(1) == 0
+    try:
+        with pytest.raises(B.BgsaHipError, match="semi-global"):
+            a = B.DeviceAligner(B.ALGO_MYERS)
+            a._select = lambda: None          # bypass the wrapper's own mode reset: the C ABI must refuse
+            a.set_queries(q)
+            a.set_subjects(s)
+            a.score()
+    finally:
+        assert L.bgsa_hip_select_alignment(0) == 0

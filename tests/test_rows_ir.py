@@ -250,3 +250,27 @@ def test_bitpal_set_generator_picks_widths_that_fit(tmp_path):
         assert plain[0] == 1 and plain == list(range(1, plain[-1] + 1)) and blocks[-1] <= 8
         assert sc.planes * plain[-1] + 5 * plain[-1] + R.bitpal_body(plain[-1], sc).allocate_temps()[1] <= G.BITPAL_VGPR_BUDGET
     assert G.bitpal_widths(R.BITPAL_DEFAULT) == ([1, 2, 3, 4, 5, 6, 7, 8], [5, 6, 7, 8])
+
+
+# ---- semi-global BitPAl (generator option -s): same row body, other first row and last-row maximum ----
+@pytest.mark.parametrize("scores", [(2, -3, -5), (0, -1, -1), (1, -3, -2), (5, -4, -10)])
+@pytest.mark.parametrize("qlen,slen", [(60, 150), (150, 150), (97, 33), (20, 200)])
+def test_bitpal_semiglobal_matches_dp(oracle, scores, qlen, slen):
+    sc = R.BitpalScores(*scores)
+    nw = (slen + 31) // 32
+    body = R.bitpal_body(nw, sc)
+    q = oracle.gen_reads(1700 + qlen, 3, qlen)
+    s = oracle.gen_reads(1800 + slen, 64, slen)
+    if slen >= qlen:   # plant the query (lightly edited) inside some subjects at various offsets
+        for r in range(20):
+            off = (r * 7) % (slen - qlen + 1)
+            s[r, off:off + qlen] = oracle.mutate(q[r % 3: r % 3 + 1], [r % 5], 1900 + r)[0]
+    peq = R.build_peq32(s, nw)
+    want = oracle.dp_semiglobal(q, s, *scores)
+    for i in range(q.shape[0]):
+        st = R.bitpal_init_state(nw, s.shape[0], sc, semi=True)
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.bitpal_score(st, nw, qlen, slen, sc, semi=True), want[i])
+        assert np.array_equal(R.bitpal_blocked_simulate(s, q[i], 2, sc, semi=True), want[i])
+    if slen >= qlen:
+        assert want[:, :20].max(axis=0).min() > want[:, 20:].max()   # the planted copies beat every random subject
