@@ -8,13 +8,15 @@ There is no CPU fallback: if the library is missing, importing the compute API r
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libbgsa_hip.so"
+# BGSA_HIP_LIB: another build of the same library (A/B measurements of generator variants)
+LIB_PATH = Path(os.environ["BGSA_HIP_LIB"]) if os.environ.get("BGSA_HIP_LIB") else HERE / "libbgsa_hip.so"
 INCLUDE = HERE.parent / "include" / "bgsa_hip.h"
 
 ALGO_MYERS, ALGO_BANDED, ALGO_BITPAL = 0, 1, 2

@@ -410,7 +410,7 @@ def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int]]:
         return sc.planes * nw + 5 * nw + R.bitpal_body(nw, sc).allocate_temps()[1]
 
     def block_regs(nw):
-        body, _ = R.make_blocked(R.bitpal_body(nw, sc), sc.planes * nw)
+        body, _ = R.bitpal_block_body(nw, sc)
         return sc.planes * nw + 5 * nw + body.allocate_temps()[1] + 2 * sc.chains + 2
 
     plain = max(nw for nw in range(1, 9) if plain_regs(nw) <= BITPAL_VGPR_BUDGET)
@@ -454,7 +454,7 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
                  "                                                      const unsigned long long carry_base,\n"
                  "                                                      const unsigned long long stream, const int n_windows);\n")
     for nw in blocks:
-        blocked, init = R.make_blocked(R.bitpal_body(nw, sc), B * nw)
+        blocked, init = R.bitpal_block_body(nw, sc)
         assert len(init) == NC and not any(init)  # every BitPAl chain starts with carry-in 0
         parts.append(gen_blocked_function("bitpal_block_rows_asm", nw, blocked, B * nw, NC, 0, nw))
     return "".join(parts)

@@ -215,6 +215,91 @@ class Body:
         return lines
 
 
+def count_hazard_nops(body: "Body") -> int:
+    """s_nop padding emit_asm() would insert: addc issued fewer than 2 instructions after a VCC write."""
+    nops, since = 0, 99
+    for op in body.ops:
+        if op.kind == "setc1":
+            since = 0
+            continue
+        if op.kind == "addc" and since < 2:
+            nops += 1
+            since = 2
+        since = 0 if op.kind in ("add_co", "addc") else since + 1
+    return nops
+
+
+def schedule(body: "Body", window: int = 48) -> "Body":
+    """List-schedule a straight-line body so that carry chains keep moving and the two wait states
+    between the links of a chain are filled with independent work instead of s_nop.
+
+    Dependencies: read-after-write, write-after-read and write-after-write on every register name
+    and on VCC (add_co / setc1 write it, addc reads and writes it), so chains stay intact and never
+    interleave.  Priority: the next chain link as soon as it is hazard-free; otherwise the earliest
+    instruction in program order that does not read VCC.  `window` bounds how far ahead of the oldest
+    unscheduled instruction a filler may be taken from — it trades nops against live registers."""
+    ops = body.ops
+    n = len(ops)
+    last_write: dict = {}
+    readers: dict = {}
+    preds = [set() for _ in range(n)]
+    for i, op in enumerate(ops):
+        reads = [r for r in op.srcs if r]
+        writes = [op.dst] if op.dst else []
+        if op.kind == "addc":
+            reads.append("VCC")
+        if op.kind in ("add_co", "addc", "setc1"):
+            writes.append("VCC")
+        for r in reads:
+            if r in last_write:
+                preds[i].add(last_write[r])
+        for w in writes:
+            if w in last_write:
+                preds[i].add(last_write[w])
+            preds[i].update(readers.get(w, ()))
+        for r in reads:
+            readers.setdefault(r, []).append(i)
+        for w in writes:
+            last_write[w] = i
+            readers[w] = []
+        preds[i].discard(i)
+    succs = [[] for _ in range(n)]
+    for i in range(n):
+        for p in preds[i]:
+            succs[p].append(i)
+    remaining = [len(preds[i]) for i in range(n)]
+    done = [False] * n
+    ready = sorted(i for i in range(n) if remaining[i] == 0)
+    order = []
+    since = 99
+    oldest = 0
+    while len(order) < n:
+        while oldest < n and done[oldest]:
+            oldest += 1
+        cands = [i for i in ready if i < oldest + window] or ready[:1]
+        chain = [i for i in cands if ops[i].kind in ("addc", "add_co", "setc1")]
+        plain = [i for i in cands if ops[i].kind != "addc"]
+        if since >= 2 and chain:
+            pick = chain[0]                      # the chain is the critical path: keep it moving
+        elif since < 2 and plain:
+            nonchain = [i for i in plain if ops[i].kind not in ("add_co", "setc1")]
+            pick = (nonchain or plain)[0]        # a wait state to fill
+        else:
+            pick = cands[0]                      # nothing to fill it with: emit_asm() pads with s_nop
+        ready.remove(pick)
+        done[pick] = True
+        order.append(pick)
+        since = 0 if ops[pick].kind in ("add_co", "addc", "setc1") else since + 1
+        for s in succs[pick]:
+            remaining[s] -= 1
+            if remaining[s] == 0:
+                ready.append(s)
+        ready.sort()
+    out = Body()
+    out.ops = [ops[i] for i in order]
+    return out
+
+
 # =================================================================================================
 # Myers unit-cost global (reference original/BGSA_CPU/align_core.c:65-132)
 # =================================================================================================
@@ -270,13 +355,14 @@ def myers_planes_body(nw: int) -> Body:
         b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
         b.OR(D(w), D(w), "e")
     b.SETC1()
-    for w in range(nw):  # phase C: HP chain; HN parks in the VP register, the new VN is final
+    for w in range(nw):  # phase C: HP chain; HN parks in the VP register
         b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
         b.AND(P(w), D(w), P(w))            # HN
         b.ADDC(HP(w), HP(w), HP(w))
-        b.AND(M(w), D(w), HP(w))
-    for w in range(nw):  # phase D: HN chain in place, then the new VP
+    for w in range(nw):  # phase D: HN chain in place, then the new VP; the new VN (needs only D and the
+        #                  shifted HP) is computed here so that every link has two instructions behind it
         (b.ADD_CO if w == 0 else b.ADDC)(P(w), P(w), P(w))
+        b.AND(M(w), D(w), HP(w))
         b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
     return b
 
@@ -307,14 +393,14 @@ def myers_block_body(nw: int) -> Body:
         b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
         b.AND(P(w), D(w), P(w))            # HN parks in the VP register
         b.ADDC(HP(w), HP(w), HP(w))
-        b.AND(M(w), D(w), HP(w))
     b.ADDC(COUT[1], COUT[1], COUT[1])
     b.ADD_CO(CIN[2], CIN[2], CIN[2])
     for w in range(nw):
         b.ADDC(P(w), P(w), P(w))
+        b.AND(M(w), D(w), HP(w))
         b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
     b.ADDC(COUT[2], COUT[2], COUT[2])
-    return b
+    return schedule(b, 16)   # fills the slots around the carry-word instructions
 
 
 def myers_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int) -> np.ndarray:
@@ -620,6 +706,7 @@ class BitpalScores:
 
 
 BITPAL_DEFAULT = BitpalScores(2, -3, -5)
+BITPAL_SCHEDULE_WINDOW = int(__import__('os').environ.get('BGSA_GEN_BITPAL_WINDOW', '48'))   # 0 = program order (A/B)
 
 
 class _Bool:
@@ -859,7 +946,8 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
                 b.XOR(dst, t(f"g{i}", w), carry)
         for i in range(B - 1):
             b.AND(H(w, i), t(f"r{i}", w), H(w, B - 1))
-    return b
+    # chains first, their wait states filled with independent work (no extra registers)
+    return schedule(b, BITPAL_SCHEDULE_WINDOW) if BITPAL_SCHEDULE_WINDOW else b
 
 
 def bitpal_scores_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT, semi: bool = False) -> list:
@@ -933,6 +1021,12 @@ def make_blocked(body: Body, n_state: int):
     return out, [c for _, c in chains]
 
 
+def bitpal_block_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT):
+    """Column-block form of bitpal_body: (body, initial carry-in per chain)."""
+    body, init = make_blocked(bitpal_body(nw, sc), sc.planes * nw)
+    return schedule(body, 200), init
+
+
 def bitpal_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     """For the default scores this is the packed kernel of original/BGSA_AVX2/align_core.c:183-428
     (same five planes, same two's complement of -(dH + 5)) at 76 fast-class VALU per word."""
@@ -958,7 +1052,7 @@ def bitpal_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: i
     nw_total = (slen + 31) // 32
     n_blocks = (nw_total + nw_block - 1) // nw_block
     peq = build_peq32(subjects, n_blocks * nw_block)
-    body, init = make_blocked(bitpal_body(nw_block, sc), B * nw_block)
+    body, init = bitpal_block_body(nw_block, sc)
     n_ch = len(init)
     assert n_ch == sc.chains and not any(init)
     code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
