@@ -240,6 +240,8 @@ class DeviceAligner:
         # the score set and the alignment mode are process-global state of the C ABI (the reference's ints)
         if self.algo == ALGO_BITPAL:
             check(lib().bgsa_hip_select_scores(*(self.scores or (2, -3, -5))), "select_scores")
+        elif lib().bgsa_hip_current_algorithm() != self.algo:
+            check(lib().bgsa_hip_select_algorithm(self.algo), "select_algorithm")
         check(lib().bgsa_hip_select_alignment(1 if self.semi_global else 0), "select_alignment")
 
     def kernel_name(self) -> str:

@@ -164,7 +164,10 @@ struct BitpalSet {
 int bitpal_set_count();
 const BitpalSet *bitpal_set_at(int i);
 const BitpalSet *bitpal_find_set(int match, int mismatch, int gap);  // nullptr: not compiled in
-const BitpalSet *bitpal_current_set();  // the set of the ABI's score globals; nullptr + error text if absent
+// The set that scores the ABI's score globals and the factor its results are multiplied by: the ints
+// divided by their common factor, as the reference's generator does (Main.java:213-267).  nullptr +
+// error text if that reduced set is not compiled in.
+const BitpalSet *bitpal_current_set(int *factor = nullptr);
 
 // Scores with the set selected by the ABI's match_score / mismatch_score / gap_score.
 int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
@@ -195,6 +198,7 @@ int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t 
 int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
                       int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream);
 int launch_map_queries(char *d_content, int64_t bytes, hipStream_t stream);
+int launch_scale_scores(int16_t *d_scores, int64_t count, int factor, hipStream_t stream);
 
 // ---- device helpers ---------------------------------------------------------------------------
 

@@ -30,14 +30,31 @@ const BitpalSet *bitpal_find_set(int match, int mismatch, int gap)
     return nullptr;
 }
 
-const BitpalSet *bitpal_current_set()
+namespace {
+int gcd3(int a, int b, int c)
 {
-    const BitpalSet *s = bitpal_find_set(match_score, mismatch_score, gap_score);
+    auto g = [](int x, int y) {
+        x = x < 0 ? -x : x;
+        y = y < 0 ? -y : y;
+        while (y) { const int r = x % y; x = y; y = r; }
+        return x;
+    };
+    return g(g(a, b), c);
+}
+}  // namespace
+
+const BitpalSet *bitpal_current_set(int *factor)
+{
+    // commonFactor() of the generator (Main.java:213-238): the largest integer dividing all three
+    int f = gcd3(match_score, mismatch_score, gap_score);
+    if (f < 1) f = 1;
+    if (factor) *factor = f;
+    const BitpalSet *s = bitpal_find_set(match_score / f, mismatch_score / f, gap_score / f);
     if (!s) {
-        char msg[192];
+        char msg[224];
         snprintf(msg, sizeof msg,
-                 "bitpal: no kernels compiled for match %d / mismatch %d / gap %d (rebuild with BITPAL_SETS, "
-                 "see bgsa_hip_score_set())", match_score, mismatch_score, gap_score);
+                 "bitpal: no kernels compiled for match %d / mismatch %d / gap %d (reduced by their common factor %d; "
+                 "rebuild with BITPAL_SETS, see bgsa_hip_score_set())", match_score / f, mismatch_score / f, gap_score / f, f);
         set_error_text(msg);
     }
     return s;
@@ -68,13 +85,18 @@ int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                   void *d_workspace, hipStream_t stream, int semi_global)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
-    const BitpalSet *s = bitpal_current_set();
+    int factor = 1;
+    const BitpalSet *s = bitpal_current_set(&factor);
     if (!s) return BGSA_HIP_EUNSUPPORTED;
+    int rc;
     if (word_num > s->max_plain && bitpal_c_impl(s) && !semi_global)  // A/B: the state-in-memory C++ kernel
-        return launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
-                           ref_end, word_num, d_workspace, stream);
-    return s->launch(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
-                     d_workspace, stream, semi_global);
+        rc = launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
+                         ref_end, word_num, d_workspace, stream);
+    else
+        rc = s->launch(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
+                       d_workspace, stream, semi_global);
+    if (rc) return rc;
+    return launch_scale_scores(d_results, static_cast<int64_t>(ref_end - ref_start) * read_count, factor, stream);
 }
 
 }  // namespace bgsa

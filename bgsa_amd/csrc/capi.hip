@@ -127,11 +127,18 @@ int bgsa_hip_current_alignment(void) { return g_alignment; }
 
 int bgsa_hip_select_scores(int match, int mismatch, int gap)
 {
-    if (!bitpal_find_set(match, mismatch, gap)) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "select_scores: no BitPAl kernels compiled for %d / %d / %d (make BITPAL_SETS=...)",
-                 match, mismatch, gap);
-        set_error_text(msg);
+    if (match == 0 && mismatch == 1 && gap == 1) {  // the generator's `-m 1`: Myers, result = +distance
+        if (int rc = bgsa_hip_select_algorithm(BGSA_ALGO_MYERS)) return rc;
+        mismatch_score = 1; gap_score = 1;
+        return BGSA_HIP_OK;
+    }
+    const int old_m = match_score, old_x = mismatch_score, old_g = gap_score;
+    match_score = match; mismatch_score = mismatch; gap_score = gap;
+    const bool ok = match > mismatch && mismatch >= 2 * gap && gap < 0 && bitpal_current_set() != nullptr;
+    match_score = old_m; mismatch_score = old_x; gap_score = old_g;
+    if (!ok) {
+        if (!(match > mismatch && mismatch >= 2 * gap && gap < 0))
+            set_error_text("select_scores: BitPAl needs match > mismatch >= 2*gap and gap < 0");
         return BGSA_HIP_EUNSUPPORTED;
     }
     if (int rc = bgsa_hip_select_algorithm(BGSA_ALGO_BITPAL)) return rc;
@@ -329,8 +336,16 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
             set_error_text("cal_align_score_dev: word_num does not match read_len for Myers");
             return BGSA_HIP_EINVAL;
         }
-        return launch_myers(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len, read_len,
-                            read_count, ref_start, ref_end, word_num, d_workspace, s);
+    {
+        // weights (0, 1, 1) — the generator's `-m 1` — report +distance; anything else (0/-1/-1, or the ints
+        // of a BitPAl selection still in place while `algo` asks for Myers) the reference's -distance
+        const bool positive = match_score == 0 && mismatch_score == 1 && gap_score == 1;
+        if (int rc = launch_myers(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len, read_len,
+                                  read_count, ref_start, ref_end, word_num, d_workspace, s))
+            return rc;
+        return launch_scale_scores(static_cast<int16_t *>(d_results), static_cast<int64_t>(ref_end - ref_start) * read_count,
+                                   positive ? -1 : 1, s);
+    }
     case BGSA_ALGO_BANDED:
         return launch_banded(d_content, d_peq, static_cast<int8_t *>(d_results), ref_len, read_len,
                              read_count, ref_start, ref_end, word_num, k, d_workspace, s);

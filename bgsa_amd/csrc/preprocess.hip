@@ -249,6 +249,41 @@ int launch_map_queries(char *d_content, int64_t bytes, hipStream_t stream)
     return BGSA_HIP_OK;
 }
 
+// ---- score scaling: the generator's `factor` (Main.java:213-267) ---------------------------------
+// The reference multiplies the final score by a constant when the kernel computed a reduced problem:
+// BitPAl scores with a common factor f run as (M/f, I/f, G/f) and the result is multiplied by f
+// (genPackedScore, BitPAlGenerator.java:121-127); Myers with weights (0, 1, 1) (`-m 1`) reports
+// +distance where `-m 0` reports -distance (genMyersScore, MyersGenerator.java:43-45).  Here that is
+// one streaming pass over the int16 tile after the scoring kernel, only when a factor is in play.
+__global__ __launch_bounds__(256) void scale_scores_kernel(int16_t *__restrict__ scores, long long n_vec8, int factor)
+{
+    const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_vec8) return;
+    uint4 v = reinterpret_cast<uint4 *>(scores)[i];
+    uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int lo = static_cast<int16_t>(w[k] & 0xffffu) * factor;
+        const int hi = static_cast<int16_t>(w[k] >> 16) * factor;
+        w[k] = (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16);
+    }
+    reinterpret_cast<uint4 *>(scores)[i] = v;
+}
+
+int launch_scale_scores(int16_t *d_scores, int64_t count, int factor, hipStream_t stream)
+{
+    if (count == 0 || factor == 1) return BGSA_HIP_OK;
+    if (count % 8) {  // tiles are [queries][multiple of 64 subjects]
+        set_error_text("scale_scores: element count must be a multiple of 8");
+        return BGSA_HIP_EINVAL;
+    }
+    const long long n_vec8 = count / 8;
+    hipLaunchKernelGGL(scale_scores_kernel, dim3(static_cast<unsigned>((n_vec8 + 255) / 256)), dim3(256), 0, stream,
+                       d_scores, n_vec8, factor);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
 // ---- host routine behind hip_handle_reads -------------------------------------------------------
 
 void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint32_t *result_reads,

@@ -297,7 +297,10 @@ int main(int argc, char **argv)
     double total_start = now(), mem_time = 0, cal_time = 0;
     if (sc_given || semi) algo = BGSA_ALGO_BITPAL;
     CK(bgsa_hip_select_algorithm(algo));
-    if (sc_given) CK(bgsa_hip_select_scores(sc_match, sc_mismatch, sc_gap));
+    if (sc_given) {
+        CK(bgsa_hip_select_scores(sc_match, sc_mismatch, sc_gap));
+        algo = bgsa_hip_current_algorithm(); /* -M 0 -I 1 -G 1 is Myers reporting +distance (generator -m 1) */
+    }
     CK(bgsa_hip_select_alignment(semi ? BGSA_ALIGN_SEMIGLOBAL : BGSA_ALIGN_GLOBAL));
     init_mapping_table();
     const size_t esz = algo == BGSA_ALGO_BANDED ? sizeof(hip_banded_write_t) : sizeof(hip_write_t);

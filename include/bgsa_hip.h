@@ -95,7 +95,11 @@ int bgsa_hip_current_algorithm(void);
  * BGSA_HIP_EUNSUPPORTED (ints unchanged) if that set was not compiled in; scoring with ints that
  * name no compiled set fails the same way.  bgsa_hip_score_set() enumerates the compiled sets
  * (index 0 = the reference's committed 2/-3/-5); valu_per_word = VALU instructions per (row, 32
- * columns) of that set's kernel.  Any out-pointer may be NULL. */
+ * columns) of that set's kernel.  Any out-pointer may be NULL.
+ * Like the generator (commonFactor, Main.java:213-267), scores with a common factor f run on the set
+ * (M/f, I/f, G/f) and the result is multiplied by f: 4/-6/-10 needs only 2/-3/-5 compiled in.
+ * bgsa_hip_select_scores(0, 1, 1) is the generator's `-m 1`: BGSA_ALGO_MYERS reporting +distance
+ * instead of -distance (the same ints written directly while Myers is selected do the same). */
 int bgsa_hip_select_scores(int match, int mismatch, int gap);
 
 /* Global (default) or semi-global scoring — the generator's `-s` option (Configuration.isSemiGlobal;

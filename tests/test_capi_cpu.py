@@ -219,3 +219,24 @@ def test_workspace_follows_the_selected_score_set(L):
         assert L.bgsa_hip_workspace_bytes(B.ALGO_BITPAL, 150, 150, 100) == plain
         assert 0 < L.bgsa_hip_workspace_bytes(B.ALGO_BITPAL, 150, 1000, 100) < blocked_default   # 3 chains vs 13
     assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+
+
+def test_scores_with_a_common_factor_use_the_reduced_set(L):
+    ints = lambda: [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")]
+    assert L.bgsa_hip_select_scores(4, -6, -10) == 0          # = 2 x (2, -3, -5), the generator's commonFactor
+    assert ints() == [4, -6, -10] and L.bgsa_hip_current_algorithm() == B.ALGO_BITPAL
+    assert L.bgsa_hip_kernel_name(B.ALGO_BITPAL, 5).startswith(b"bitpal_asm_kernel<5>")
+    assert L.bgsa_hip_select_scores(6, -9, -15) == 0
+    assert L.bgsa_hip_select_scores(4, -6, -11) != 0           # no common factor, and not compiled
+    assert ints() == [6, -9, -15]
+    assert L.bgsa_hip_select_scores(1, 1, -1) != 0 and b"match > mismatch" in L.bgsa_hip_last_error()
+    assert L.bgsa_hip_select_scores(2, -9, -4) != 0            # mismatch below two gaps: outside the method
+    assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+
+
+def test_myers_positive_weights_are_the_generators_m1(L):
+    assert L.bgsa_hip_select_scores(0, 1, 1) == 0
+    assert L.bgsa_hip_current_algorithm() == B.ALGO_MYERS
+    assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [0, 1, 1]
+    assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+    assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [0, -1, -1]

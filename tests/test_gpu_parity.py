@@ -396,3 +396,36 @@ def test_semiglobal_is_refused_for_other_algorithms_and_does_not_stick(oracle):
             a.score()
     finally:
         assert L.bgsa_hip_select_alignment(0) == 0
+
+
+# ---- the generator's `factor` (Main.java:213-267): reduced score sets and Myers +distance ----------------
+@pytest.mark.parametrize("qlen,slen", [(150, 150), (60, 300)])
+def test_scores_with_common_factor(oracle, qlen, slen):
+    q = oracle.gen_reads(41, 5, qlen)
+    s = _related(oracle, q, 130, slen, 42)
+    got = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=(4, -6, -10))
+    assert np.array_equal(got, oracle.dp_nw(q, s, 4, -6, -10))
+    assert np.array_equal(got, 2 * oracle.bitpal(q, s).astype(np.int32))
+    semi = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=(6, -9, -15), semi_global=True)
+    assert np.array_equal(semi, oracle.dp_semiglobal(q, s, 6, -9, -15))
+    if (0, -1, -1) in B.score_sets():
+        assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=(0, -3, -3)), 3 * oracle.myers64(q, s).astype(np.int32))
+
+
+@pytest.mark.parametrize("slen", [150, 600, 2500])
+def test_myers_positive_distance(oracle, slen):
+    q = oracle.gen_reads(43, 4, 150)
+    s = _related(oracle, q, 130, slen, 44)
+    L = B.lib()
+    a = B.DeviceAligner(B.ALGO_MYERS)
+    a.set_queries(q)
+    a.set_subjects(s)
+    neg = a.score()[:, :130].cpu().numpy()
+    assert np.array_equal(neg, oracle.myers64(q, s))
+    assert L.bgsa_hip_select_scores(0, 1, 1) == 0               # generator option -m 1
+    try:
+        pos = a.score()[:, :130].cpu().numpy()
+    finally:
+        assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+    assert np.array_equal(pos, -neg) and (pos >= 0).all()
+    assert np.array_equal(pos, -oracle.dp_edit(q, s).astype(np.int32))   # dp_edit follows the reference sign: -distance
