@@ -169,14 +169,17 @@ class DeviceAligner:
     def __init__(self, algo: int = ALGO_MYERS, device: str = "cuda:0", k: int = 0, scores=None,
                  semi_global: bool = False):
         """scores: (match, mismatch, gap) for ALGO_BITPAL; None = the reference's 2 / -3 / -5.
-        semi_global: ALGO_BITPAL only — query end to end, free subject overhangs (generator -s)."""
+        semi_global (generator -s): ALGO_BITPAL — query end to end, free subject overhangs;
+        ALGO_MYERS — subject end to end inside the query (the generator's orientations differ)."""
         import torch
         self.torch = torch
         self.algo, self.k = algo, int(k)
         self.scores = tuple(int(x) for x in scores) if scores is not None else None
         self.semi_global = bool(semi_global)
-        if (self.scores is not None or self.semi_global) and algo != ALGO_BITPAL:
-            raise BgsaHipError("scores / semi_global only apply to ALGO_BITPAL")
+        if self.scores is not None and algo != ALGO_BITPAL:
+            raise BgsaHipError("scores only apply to ALGO_BITPAL")
+        if self.semi_global and algo == ALGO_BANDED:
+            raise BgsaHipError("semi_global is not defined for the banded filter")
         self.device = torch.device(device)
         if not torch.cuda.is_available():
             raise BgsaHipError("no GPU visible: the HIP path has no CPU fallback")

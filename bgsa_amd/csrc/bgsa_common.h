@@ -29,7 +29,7 @@ void set_error_text(const char *text);
 // Launchers implemented in the per-algorithm .hip files.  All pointers are device pointers.
 int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                 void *d_workspace, hipStream_t stream);
+                 void *d_workspace, hipStream_t stream, int semi_global = 0);
 const char *myers_kernel_name(int word_num);
 
 // Packed query stream (one per query, 8-byte windows): codes 0..4 = A C G T N row, 5 = END,

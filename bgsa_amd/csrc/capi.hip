@@ -315,8 +315,8 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         set_error_text("cal_align_score_dev: bad argument (read_count must be a multiple of 64)");
         return BGSA_HIP_EINVAL;
     }
-    if (g_alignment == BGSA_ALIGN_SEMIGLOBAL && algo != BGSA_ALGO_BITPAL) {
-        set_error_text("cal_align_score_dev: semi-global alignment is implemented for BGSA_ALGO_BITPAL only");
+    if (g_alignment == BGSA_ALIGN_SEMIGLOBAL && algo == BGSA_ALGO_BANDED) {
+        set_error_text("cal_align_score_dev: semi-global alignment is not defined for the banded filter");
         return BGSA_HIP_EUNSUPPORTED;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -341,7 +341,8 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         // of a BitPAl selection still in place while `algo` asks for Myers) the reference's -distance
         const bool positive = match_score == 0 && mismatch_score == 1 && gap_score == 1;
         if (int rc = launch_myers(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len, read_len,
-                                  read_count, ref_start, ref_end, word_num, d_workspace, s))
+                                  read_count, ref_start, ref_end, word_num, d_workspace, s,
+                                  g_alignment == BGSA_ALIGN_SEMIGLOBAL))
             return rc;
         return launch_scale_scores(static_cast<int16_t *>(d_results), static_cast<int64_t>(ref_end - ref_start) * read_count,
                                    positive ? -1 : 1, s);

@@ -34,9 +34,14 @@
 namespace bgsa {
 
 // One DP row: in-place update of the vertical delta vectors for query character class `eq`.
-template <int NW, int G>
+// SEMI (the generator's `-s` for Myers, MyersGenerator.java:56-223): the row boundary feeds 0 instead
+// of +1 into word 0 (D[0][i] = 0: the subject may start anywhere in the query) and the horizontal delta
+// leaving the last subject column (bit `last_bit` of the last word's HP / HN) is handed back, so the
+// caller can follow D[n][i] row by row.
+template <int NW, int G, bool SEMI = false>
 __device__ __forceinline__ void myers_row(uint32_t (&vp)[G * NW], uint32_t (&vn)[G * NW],
-                                          const uint32_t (&eq)[G * NW])
+                                          const uint32_t (&eq)[G * NW], int last_word = 0, int last_bit = 0,
+                                          int *delta = nullptr)
 {
 #pragma unroll
   for (int gi = 0; gi < G; gi++) {
@@ -55,12 +60,14 @@ __device__ __forceinline__ void myers_row(uint32_t (&vp)[G * NW], uint32_t (&vn)
         const uint32_t hp = ~(d0 | pv) | mv;
         const uint32_t hn = d0 & pv;
         // Shift one column along the subject; row boundary D[i][0]-D[i-1][0] = +1 enters word 0.
-        const uint32_t hps = (ww == 0) ? ((hp << 1) | 1u) : ((hp << 1) | (hp_prev >> 31));
+        const uint32_t hps = (ww == 0) ? ((hp << 1) | (SEMI ? 0u : 1u)) : ((hp << 1) | (hp_prev >> 31));
         const uint32_t hns = (ww == 0) ? (hn << 1) : ((hn << 1) | (hn_prev >> 31));
         hp_prev = hp;
         hn_prev = hn;
         vp[w] = ~(d0 | hps) | hns;
         vn[w] = d0 & hps;
+        if (SEMI && ww == last_word)
+            delta[gi] = static_cast<int>((hp >> last_bit) & 1u) - static_cast<int>((hn >> last_bit) & 1u);
     }
   }
 }
@@ -68,7 +75,7 @@ __device__ __forceinline__ void myers_row(uint32_t (&vp)[G * NW], uint32_t (&vn)
 // grid.x = ceil(n_groups / (4*G)), grid.y = number of query tiles; block = 4 waves, each wave
 // owns G consecutive groups (G subjects per lane): the scalar work of a row (character fetch,
 // 5-way branch) is shared by G x NW word updates.
-template <int NW, int G>
+template <int NW, int G, bool SEMI = false>
 __global__ __launch_bounds__(256) void myers_global_kernel(
     const char *__restrict__ content, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     int ref_len, int read_len, long long ld, int n_groups, int word_num, int ref_start,
@@ -104,16 +111,36 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
             vn[w] = 0u;
         }
         UniformBytes qs(content + static_cast<size_t>(q) * (ref_len + 1));
+        // semi-global: run[gi] = D[n][i], the subject against the query prefix ending at row i;
+        // best = its minimum, starting from D[n][0] = n (genSemiGlobal: score = read_len, min_score = score)
+        const int last_word = (read_len - 1) >> 5, last_bit = (read_len - 1) & 31;
+        int run[G], best[G], delta[G];
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) run[gi] = best[gi] = read_len;
         for (int r = 0; r < ref_len; r++) {
             if ((r & 3) == 0) qs.refill(r, ref_len - r);
             const uint32_t c = __builtin_amdgcn_readfirstlane(qs.next());
             switch (c) {
-            case 0: myers_row<NW, G>(vp, vn, P[0]); break;
-            case 1: myers_row<NW, G>(vp, vn, P[1]); break;
-            case 2: myers_row<NW, G>(vp, vn, P[2]); break;
-            case 3: myers_row<NW, G>(vp, vn, P[3]); break;
-            default: myers_row<NW, G>(vp, vn, P[4]); break;
+            case 0: myers_row<NW, G, SEMI>(vp, vn, P[0], last_word, last_bit, delta); break;
+            case 1: myers_row<NW, G, SEMI>(vp, vn, P[1], last_word, last_bit, delta); break;
+            case 2: myers_row<NW, G, SEMI>(vp, vn, P[2], last_word, last_bit, delta); break;
+            case 3: myers_row<NW, G, SEMI>(vp, vn, P[3], last_word, last_bit, delta); break;
+            default: myers_row<NW, G, SEMI>(vp, vn, P[4], last_word, last_bit, delta); break;
             }
+            if (SEMI) {
+#pragma unroll
+                for (int gi = 0; gi < G; gi++) {
+                    run[gi] += delta[gi];
+                    best[gi] = run[gi] < best[gi] ? run[gi] : best[gi];
+                }
+            }
+        }
+        if (SEMI) {
+#pragma unroll
+            for (int gi = 0; gi < G; gi++)
+                if (group0 + gi < n_groups)
+                    dst[static_cast<size_t>(q - ref_start) * ld + gi * kLanes] = static_cast<int16_t>(-best[gi]);
+            continue;
         }
         // D[m][n] = m + sum over the n subject columns of (VP - VN).
 #pragma unroll
@@ -443,7 +470,7 @@ int pick_planes_nw(int word_num)
     return -1;
 }
 
-template <int NW, int G>
+template <int NW, int G, bool SEMI = false>
 int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
               int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
               hipStream_t stream)
@@ -457,7 +484,7 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
         set_error_text("myers: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL((myers_global_kernel<NW, G>), grid, dim3(256), 0, stream, d_content, d_peq,
+    hipLaunchKernelGGL((myers_global_kernel<NW, G, SEMI>), grid, dim3(256), 0, stream, d_content, d_peq,
                        d_results, ref_len, read_len, static_cast<long long>(read_count),
                        static_cast<int>(n_groups), word_num, ref_start, ref_end, q_tile);
     BGSA_HIP_TRY(hipGetLastError());
@@ -484,9 +511,24 @@ const char *myers_kernel_name(int word_num)
 
 int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
-                 void *d_workspace, hipStream_t stream)
+                 void *d_workspace, hipStream_t stream, int semi_global)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
+    if (semi_global) {  // compiler-scheduled kernel only: subjects up to 1024 bp
+        switch (pick_nw(word_num)) {
+#define BGSA_CASE(N)                                                                            \
+    case N:                                                                                     \
+        return launch_nw<N, 1, true>(d_content, d_peq, d_results, ref_len, read_len, read_count, \
+                                     ref_start, ref_end, word_num, stream);
+            BGSA_CASE(1) BGSA_CASE(2) BGSA_CASE(3) BGSA_CASE(4) BGSA_CASE(5) BGSA_CASE(6)
+            BGSA_CASE(7) BGSA_CASE(8) BGSA_CASE(10) BGSA_CASE(12) BGSA_CASE(14) BGSA_CASE(16)
+            BGSA_CASE(20) BGSA_CASE(24) BGSA_CASE(28) BGSA_CASE(32)
+#undef BGSA_CASE
+        default:
+            set_error_text("myers: semi-global scoring is implemented for subjects up to 1024 bp");
+            return BGSA_HIP_EUNSUPPORTED;
+        }
+    }
     if (word_num > kMaxWords && myers_impl() == 1)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_MYERS, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);

@@ -151,7 +151,7 @@ static void usage(void)
     printf("  -k <arg>\n\t Filter threshold (banded). \n\n");
     printf("  -a <arg>\n\t Algorithm: myers (default), banded, bitpal. \n\n");
     printf("  -M <arg> -I <arg> -G <arg>\n\t BitPAl match / mismatch / gap scores (a set the library was built with;\n\t default 2 / -3 / -5). Implies -a bitpal. \n\n");
-    printf("  -s\n\t Semi-global BitPAl: query end to end, free subject overhangs (implies -a bitpal). \n\n");
+    printf("  -s\n\t Semi-global: BitPAl - query end to end inside the subject; Myers - subject end to end\n\t inside the query (the generator's two orientations). \n\n");
     printf("  -n <arg>\n\t Number of GPUs. Default 1. \n\n");
     printf("  -g <arg>\n\t First GPU index, or a comma separated list of GPU indices. Default 0. \n\n");
     printf("  -R <arg>\n\t File with one work ratio per GPU (one number per line). Default: equal. \n\n");
@@ -295,7 +295,7 @@ int main(int argc, char **argv)
     }
 
     double total_start = now(), mem_time = 0, cal_time = 0;
-    if (sc_given || semi) algo = BGSA_ALGO_BITPAL;
+    if (sc_given) algo = BGSA_ALGO_BITPAL;
     CK(bgsa_hip_select_algorithm(algo));
     if (sc_given) {
         CK(bgsa_hip_select_scores(sc_match, sc_mismatch, sc_gap));

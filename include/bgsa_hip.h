@@ -102,11 +102,16 @@ int bgsa_hip_current_algorithm(void);
  * instead of -distance (the same ints written directly while Myers is selected do the same). */
 int bgsa_hip_select_scores(int match, int mismatch, int gap);
 
-/* Global (default) or semi-global scoring — the generator's `-s` option (Configuration.isSemiGlobal;
- * BitPAlGenerator.java:2201-2218 first row, :78-116 last-row maximum): the query is aligned end to
- * end, subject overhangs before and after it are free, result = max over the last DP row.
- * Implemented for BGSA_ALGO_BITPAL (any compiled score set); scoring another algorithm while
- * semi-global is selected returns BGSA_HIP_EUNSUPPORTED.  Process-global like the score ints. */
+/* Global (default) or semi-global scoring — the generator's `-s` option (Configuration.isSemiGlobal).
+ * The two generators orient it differently, and so does this library:
+ *   BGSA_ALGO_BITPAL (BitPAlGenerator.java:2201-2218 first row, :78-116 last-row maximum): the QUERY is
+ *     aligned end to end, subject overhangs before and after it are free; result = max over the last DP
+ *     row.  Any compiled score set, any length.
+ *   BGSA_ALGO_MYERS (MyersGenerator.java:56-223 genSemiGlobal): the SUBJECT is aligned end to end inside
+ *     the query (D[0][y] = 0, result = -min over y of D[slen][y]); subjects up to 1024 bp
+ *     (compiler-scheduled kernel), longer ones return BGSA_HIP_EUNSUPPORTED.
+ *   BGSA_ALGO_BANDED: not defined, BGSA_HIP_EUNSUPPORTED.
+ * Process-global like the score ints. */
 enum { BGSA_ALIGN_GLOBAL = 0, BGSA_ALIGN_SEMIGLOBAL = 1 };
 int bgsa_hip_select_alignment(int mode);
 int bgsa_hip_current_alignment(void);

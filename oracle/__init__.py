@@ -44,7 +44,7 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(str(LIB_PATH))
         c_p, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         common = [c_p, i64, i32, c_p, i64, i32]
-        for name in ("myers64", "myers31", "bitpal", "dp_edit"):
+        for name in ("myers64", "myers31", "bitpal", "dp_edit", "dp_edit_semiglobal"):
             f = getattr(L, "bgsa_oracle_" + name)
             f.argtypes = common + [c_p, i32]
             f.restype = None
@@ -109,6 +109,12 @@ def banded64(q, s, k, threads=0):
 
 def dp_edit(q, s, threads=0):
     return _run("dp_edit", q, s, np.int16, threads=threads)[0]
+
+
+def dp_edit_semiglobal(q, s, threads=0):
+    """-(lowest edit distance of the whole subject against any query substring ending anywhere):
+    the generator's Myers semi-global mode."""
+    return _run("dp_edit_semiglobal", q, s, np.int16, threads=threads)[0]
 
 
 def dp_nw(q, s, match=2, mismatch=-3, gap=-5, threads=0):

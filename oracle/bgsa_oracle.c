@@ -539,6 +539,49 @@ void bgsa_oracle_dp_edit(const char *queries, int64_t nq, int qlen, const char *
     free(q); free(s);
 }
 
+/*
+ * Semi-global unit-cost DP as the reference's generator defines it for Myers (`-m 0 -s`,
+ * MyersGenerator.java:56-223 genSemiGlobal): the subject is the pattern (VP starts all ones:
+ * D[x][0] = x), the query is the text (h_in = 0 on every row: D[0][y] = 0), and the kernel keeps
+ * the minimum of D[slen][y] over y = 0..qlen, starting from D[slen][0] = slen (:115-117, :205-208).
+ * Result = -min (factor -1 as for the global kernel).  Note the orientation: here the SUBJECT is
+ * aligned end to end inside the query — the opposite of BitPAl's semi-global above.
+ */
+void bgsa_oracle_dp_edit_semiglobal(const char *queries, int64_t nq, int qlen, const char *subjects,
+                                    int64_t ns, int slen, int16_t *out, int threads)
+{
+    if (nq <= 0 || ns <= 0) return;
+    uint8_t *q = map_rows(queries, nq, qlen);
+    uint8_t *s = map_rows(subjects, ns, slen);
+#pragma omp parallel num_threads(pick_threads(threads))
+    {
+        int *row = (int *)malloc(sizeof(int) * (size_t)(slen + 1));
+#pragma omp for schedule(dynamic, 16) collapse(2)
+        for (int64_t i = 0; i < nq; i++)
+            for (int64_t j = 0; j < ns; j++) {
+                const uint8_t *a = q + i * qlen, *b = s + j * slen;
+                for (int x = 0; x <= slen; x++) row[x] = x;
+                int lowest = row[slen];
+                for (int y = 1; y <= qlen; y++) {
+                    int diag = row[0];
+                    row[0] = 0;
+                    for (int x = 1; x <= slen; x++) {
+                        int up = row[x];
+                        int best = diag + (a[y - 1] != b[x - 1]);
+                        if (up + 1 < best) best = up + 1;
+                        if (row[x - 1] + 1 < best) best = row[x - 1] + 1;
+                        row[x] = best;
+                        diag = up;
+                    }
+                    if (row[slen] < lowest) lowest = row[slen];
+                }
+                out[i * ns + j] = (int16_t)(-lowest);
+            }
+        free(row);
+    }
+    free(q); free(s);
+}
+
 void bgsa_oracle_dp_nw(const char *queries, int64_t nq, int qlen, const char *subjects,
                        int64_t ns, int slen, int match, int mismatch, int gap, int16_t *out,
                        int threads)

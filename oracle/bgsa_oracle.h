@@ -68,6 +68,10 @@ void bgsa_oracle_bitpal(const char *queries, int64_t nq, int qlen,
 void bgsa_oracle_dp_edit(const char *queries, int64_t nq, int qlen,
                          const char *subjects, int64_t ns, int slen,
                          int16_t *out, int threads);
+/* -min over query prefixes y of D[slen][y], D[x][0] = x, D[0][y] = 0 (the generator's Myers -s). */
+void bgsa_oracle_dp_edit_semiglobal(const char *queries, int64_t nq, int qlen,
+                         const char *subjects, int64_t ns, int slen,
+                         int16_t *out, int threads);
 /* Needleman-Wunsch, linear gap. */
 void bgsa_oracle_dp_nw(const char *queries, int64_t nq, int qlen,
                        const char *subjects, int64_t ns, int slen,

@@ -155,6 +155,17 @@ def test_cli_semiglobal(tmp_path, oracle):
     for r in range(10):
         s[r, 9 * r: 9 * r + 60] = q[r % 5]
     g = {"queries": q, "subjects": s, "variant": "original_avx2", "k": -1}
-    got, _ = _run_cli(tmp_path, g, extra_args=["-s"])
+    got, _ = _run_cli(tmp_path, g, extra_args=["-s"])     # variant original_avx2 -> -a bitpal
     assert np.array_equal(got, oracle.dp_semiglobal(q, s))
     assert (got[np.arange(10) % 5, np.arange(10)] == 120).all()     # exact copies: 60 matches x 2
+
+
+def test_cli_semiglobal_myers(tmp_path, oracle):
+    q = oracle.gen_reads(63, 5, 200)
+    s = oracle.gen_reads(64, 100, 60)
+    for r in range(10):
+        s[r] = q[r % 5, 11 * r: 11 * r + 60]
+    g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
+    got, _ = _run_cli(tmp_path, g, extra_args=["-s"])
+    assert np.array_equal(got, oracle.dp_edit_semiglobal(q, s))
+    assert (got[np.arange(10) % 5, np.arange(10)] == 0).all()     # exact windows of the query

@@ -379,7 +379,7 @@ def test_bitpal_semiglobal_vs_dp(oracle, scores, qlen, slen):
 def test_semiglobal_is_refused_for_other_algorithms_and_does_not_stick(oracle):
     q, s = oracle.gen_reads(1, 3, 80), oracle.gen_reads(2, 64, 80)
     with pytest.raises(B.BgsaHipError):
-        B.DeviceAligner(B.ALGO_MYERS, semi_global=True)
+        B.DeviceAligner(B.ALGO_BANDED, k=8, semi_global=True)
     semi = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, semi_global=True)
     assert np.array_equal(semi, oracle.dp_semiglobal(q, s))
     # the mode is process-global in the C ABI; the next aligner sets its own
@@ -389,7 +389,7 @@ def test_semiglobal_is_refused_for_other_algorithms_and_does_not_stick(oracle):
     assert L.bgsa_hip_select_alignment(1) == 0
     try:
         with pytest.raises(B.BgsaHipError, match="semi-global"):
-            a = B.DeviceAligner(B.ALGO_MYERS)
+            a = B.DeviceAligner(B.ALGO_BANDED, k=8)
             a._select = lambda: None          # bypass the wrapper's own mode reset: the C ABI must refuse
             a.set_queries(q)
             a.set_subjects(s)
@@ -429,3 +429,26 @@ def test_myers_positive_distance(oracle, slen):
         assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
     assert np.array_equal(pos, -neg) and (pos >= 0).all()
     assert np.array_equal(pos, -oracle.dp_edit(q, s).astype(np.int32))   # dp_edit follows the reference sign: -distance
+
+
+# ---- semi-global Myers (generator -m 0 -s): the subject end to end inside the query --------------------
+@pytest.mark.parametrize("qlen,slen", [(200, 60), (150, 150), (33, 97), (1, 1), (500, 250), (1000, 300), (700, 1000), (300, 1024)])
+def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
+    q = oracle.gen_reads(600 + qlen, 4, qlen)
+    s = oracle.gen_reads(700 + slen, 130, slen)
+    if qlen >= slen:
+        for r in range(24):   # the subject = a lightly edited window of a query
+            off = (r * 17) % (qlen - slen + 1)
+            s[r] = oracle.mutate(q[r % 4: r % 4 + 1, off:off + slen], [r % 6], 800 + r)[0]
+    got = B.align_all_pairs(q, s, algo=B.ALGO_MYERS, semi_global=True)
+    want = oracle.dp_edit_semiglobal(q, s)
+    assert np.array_equal(got, want)
+    if qlen >= slen:
+        assert (got[np.arange(24) % 4, np.arange(24)] >= -10).all()     # found: about the planted edits, far from random (~ -0.45 slen)
+    # and the mode does not leak into the next global call
+    assert np.array_equal(B.align_all_pairs(q[:1], s, algo=B.ALGO_MYERS), oracle.myers64(q[:1], s))
+
+
+def test_myers_semiglobal_beyond_1024_is_refused(oracle):
+    with pytest.raises(B.BgsaHipError, match="1024"):
+        B.align_all_pairs(oracle.gen_reads(1, 2, 100), oracle.gen_reads(2, 64, 1100), algo=B.ALGO_MYERS, semi_global=True)
