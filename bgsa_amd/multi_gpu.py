@@ -95,15 +95,17 @@ class RatioBalancer:
 
 
 class ShardedAligner:
-    def __init__(self, dist=None, device=None, score_fn=None, algo: int = 0, k: int = 0):
-        """dist: the torch.distributed module with an initialised process group, or None for 1 rank."""
+    def __init__(self, dist=None, device=None, score_fn=None, algo: int = 0, k: int = 0, scores=None,
+                 semi_global: bool = False):
+        """dist: the torch.distributed module with an initialised process group, or None for 1 rank.
+        scores / semi_global: as bgsa_amd.DeviceAligner (BitPAl score set, generator -s)."""
         import torch
         self.torch = torch
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.device = torch.device(device) if device is not None else torch.device("cpu")
-        self.algo, self.k = algo, k
+        self.algo, self.k, self.scores, self.semi_global = algo, k, scores, semi_global
         self.score_fn = score_fn if score_fn is not None else self._hip_score
         self._aligner = None
 
@@ -111,7 +113,7 @@ class ShardedAligner:
     def _hip_score(self, queries: np.ndarray, subjects: np.ndarray):
         import bgsa_amd as B
         if self._aligner is None:
-            self._aligner = B.DeviceAligner(self.algo, str(self.device), self.k)
+            self._aligner = B.DeviceAligner(self.algo, str(self.device), self.k, self.scores, self.semi_global)
         a = self._aligner
         a.set_queries(queries)
         a.set_subjects(subjects)
