@@ -72,7 +72,7 @@ def issued_valu_per_row(algo: int, wn: int, scores=None):
     if algo == B.ALGO_MYERS and wn <= 8:
         return R.myers_body(wn).valu_count()
     if algo == B.ALGO_MYERS and wn <= 32:
-        nw = next(n for n in (12, 16, 20, 24, 28, 32) if n >= wn)
+        nw = next(n for n in range(10, 33, 2) if n >= wn)
         return R.myers_planes_body(nw).valu_count()
     if algo == B.ALGO_BITPAL and wn <= 8:
         return R.bitpal_body(wn, R.BitpalScores(*scores) if scores else R.BITPAL_DEFAULT).valu_count()

@@ -175,6 +175,9 @@ int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                   void *d_workspace, hipStream_t stream, int semi_global);
 const char *bitpal_kernel_name(int word_num);
 
+// Widest subject (in words) the Myers kernels keep whole in registers; wider ones run as column blocks.
+int myers_max_plain_words();
+
 // long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.
 inline bool beyond_registers(int algo, int word_num)
 {
@@ -182,7 +185,7 @@ inline bool beyond_registers(int algo, int word_num)
         const BitpalSet *s = bitpal_current_set();
         return s && word_num > s->max_plain;
     }
-    return algo == BGSA_ALGO_MYERS && word_num > kMaxWords;
+    return algo == BGSA_ALGO_MYERS && word_num > myers_max_plain_words();
 }
 // Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.
 constexpr int kBlockedBlocks = 512;  // persistent workgroups of myers_blocked_kernel

@@ -454,7 +454,7 @@ int pick_block_nw(int word_num, int *n_blocks)
     constexpr int kWidest = 28;
     const int blocks = (word_num + kWidest - 1) / kWidest;
     const int need = (word_num + blocks - 1) / blocks;
-    for (int nw : {20, 24, 28})
+    for (int nw : {12, 16, 20, 24, 28})
         if (nw >= need) {
             *n_blocks = (word_num + nw - 1) / nw;
             return nw;
@@ -465,7 +465,7 @@ int pick_block_nw(int word_num, int *n_blocks)
 
 int pick_planes_nw(int word_num)
 {
-    for (int nw : {12, 16, 20, 24, 28, 32})
+    for (int nw : {10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32})
         if (nw >= word_num) return nw;
     return -1;
 }
@@ -493,11 +493,21 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
 
 }  // namespace
 
+int myers_max_plain_words()
+{
+    static const int limit = [] {
+        const char *e = getenv("BGSA_MYERS_MAX_PLAIN_WORDS");   // measurement knob
+        const int v = e ? atoi(e) : kMaxWords;
+        return (v >= 8 && v <= kMaxWords) ? v : kMaxWords;
+    }();
+    return limit;
+}
+
 const char *myers_kernel_name(int word_num)
 {
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
-    if (word_num > kMaxWords) {
+    if (word_num > myers_max_plain_words()) {
         int n_blocks = 0;
         snprintf(name, sizeof name, "myers_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
         return name;
@@ -529,17 +539,17 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             return BGSA_HIP_EUNSUPPORTED;
         }
     }
-    if (word_num > kMaxWords && myers_impl() == 1)  // A/B: the state-in-memory C++ kernel
+    if (word_num > myers_max_plain_words() && myers_impl() == 1)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_MYERS, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);
-    if (word_num > kMaxWords) {
+    if (word_num > myers_max_plain_words()) {
         int n_blocks = 0;
         switch (pick_block_nw(word_num, &n_blocks)) {
 #define BGSA_BLOCK_CASE(N)                                                                       \
     case N:                                                                                      \
         return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
                                  ref_end, word_num, n_blocks, d_workspace, stream);
-            BGSA_BLOCK_CASE(20) BGSA_BLOCK_CASE(24) BGSA_BLOCK_CASE(28)
+            BGSA_BLOCK_CASE(12) BGSA_BLOCK_CASE(16) BGSA_BLOCK_CASE(20) BGSA_BLOCK_CASE(24) BGSA_BLOCK_CASE(28)
 #undef BGSA_BLOCK_CASE
         default: break;
         }
@@ -560,8 +570,9 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
     case N:                                                                                     \
         return launch_planes<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,     \
                                 ref_start, ref_end, word_num, d_workspace, stream);
-            BGSA_PLANES_CASE(12) BGSA_PLANES_CASE(16) BGSA_PLANES_CASE(20) BGSA_PLANES_CASE(24)
-            BGSA_PLANES_CASE(28) BGSA_PLANES_CASE(32)
+            BGSA_PLANES_CASE(10) BGSA_PLANES_CASE(12) BGSA_PLANES_CASE(14) BGSA_PLANES_CASE(16)
+            BGSA_PLANES_CASE(18) BGSA_PLANES_CASE(20) BGSA_PLANES_CASE(22) BGSA_PLANES_CASE(24)
+            BGSA_PLANES_CASE(26) BGSA_PLANES_CASE(28) BGSA_PLANES_CASE(30) BGSA_PLANES_CASE(32)
 #undef BGSA_PLANES_CASE
         default: break;
         }
