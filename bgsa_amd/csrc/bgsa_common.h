@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 
 #include "../../include/bgsa_hip.h"
@@ -188,7 +189,18 @@ inline bool beyond_registers(int algo, int word_num)
     return algo == BGSA_ALGO_MYERS && word_num > myers_max_plain_words();
 }
 // Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.
-constexpr int kBlockedBlocks = 512;  // persistent workgroups of myers_blocked_kernel
+// Persistent workgroups of the column-block kernels (each owns a carry buffer slice): 512 = two per CU.
+// BGSA_BLOCKED_WORKGROUPS overrides it for measurements.
+inline int blocked_workgroups()
+{
+    static const int n = [] {
+        const char *e = getenv("BGSA_BLOCKED_WORKGROUPS");
+        const int v = e ? atoi(e) : 512;
+        return (v >= 1 && v <= 65535) ? v : 512;
+    }();
+    return n;
+}
+#define kBlockedBlocks (::bgsa::blocked_workgroups())
 inline size_t blocked_carry_bytes(int ref_len, int n_chains)
 {
     return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * kBlockedBlocks;

@@ -33,7 +33,7 @@ import rows_ir as R  # noqa: E402
 
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8]
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word
-MYERS_BLOCK_NW = [12, 16, 20, 24, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
+MYERS_BLOCK_NW = [12, 14, 16, 18, 20, 22, 24, 26, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
 BITPAL_VGPR_BUDGET = 224        # state + masks + temporaries a plain BitPAl kernel may hold
 BITPAL_BLOCK_VGPR_BUDGET = 200  # same + carry words for a column-block kernel (hipcc adds ~25 around the asm)
 

@@ -454,7 +454,7 @@ int pick_block_nw(int word_num, int *n_blocks)
     constexpr int kWidest = 28;
     const int blocks = (word_num + kWidest - 1) / kWidest;
     const int need = (word_num + blocks - 1) / blocks;
-    for (int nw : {12, 16, 20, 24, 28})
+    for (int nw : {12, 14, 16, 18, 20, 22, 24, 26, 28})
         if (nw >= need) {
             *n_blocks = (word_num + nw - 1) / nw;
             return nw;
@@ -549,7 +549,8 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
     case N:                                                                                      \
         return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
                                  ref_end, word_num, n_blocks, d_workspace, stream);
-            BGSA_BLOCK_CASE(12) BGSA_BLOCK_CASE(16) BGSA_BLOCK_CASE(20) BGSA_BLOCK_CASE(24) BGSA_BLOCK_CASE(28)
+            BGSA_BLOCK_CASE(12) BGSA_BLOCK_CASE(14) BGSA_BLOCK_CASE(16) BGSA_BLOCK_CASE(18) BGSA_BLOCK_CASE(20)
+            BGSA_BLOCK_CASE(22) BGSA_BLOCK_CASE(24) BGSA_BLOCK_CASE(26) BGSA_BLOCK_CASE(28)
 #undef BGSA_BLOCK_CASE
         default: break;
         }
