@@ -63,12 +63,25 @@ __host__ __device__ inline unsigned long long plain_stream_window(const char *ro
 int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
                         void *d_streams, hipStream_t stream);
 
-// Banded stream (rows_ir.py:banded_tokens): row codes plus EVENT tokens {7, bits}: 1 = reset the
-// error count (row k), 2 = advance the match-string words (every 32 rows), 4 = test the limit on
-// all lanes, 8 = latch the reject mask (the reference's last checkpoint).  A two-byte token never
-// straddles a window: the window is closed early with a REFILL instead.  Writes the stream when
-// dst != nullptr (row = mapped query characters); returns its length in bytes including the
-// spare window.  The same routine sizes the workspace on the host and fills it on the device.
+// Banded stream (rows_ir.py: banded_tokens / banded_stream_codes).  The banded row is short (12 VALU),
+// so the scalar work of the threaded-code dispatch is what its loop waits for; one token therefore
+// carries TWO consecutive rows whenever nothing has to happen between them:
+//   0..24   two rows, classes a then b: 5*a + b        25..29  one row of class c: 25 + c
+//   30 END  31 REFILL  32 EVENT, followed by an argument byte of bits: 1 = reset the error count
+//   (row k), 2 = advance the match-string words (every 32 rows), 4 = test the limit on all lanes,
+//   8 = latch the reject mask (the reference's last checkpoint).
+// A two-byte token never straddles a window: the window is closed early with a REFILL instead.
+// Writes the stream when dst != nullptr (row = mapped query characters); returns its length in bytes
+// including the spare window.  The same routine sizes the workspace on the host and fills it on the
+// device.
+constexpr int kBandedSingle = 25, kBandedEnd = 30, kBandedRefill = 31, kBandedEvent = 32;
+// Upper bound of banded_stream_layout(len, k) over every k (sizes the workspace, which does not know k):
+// all rows as one-row tokens, every event two bytes plus one byte lost to an early window close.
+inline size_t banded_stream_bound(int len)
+{
+    const size_t events = static_cast<size_t>(len) / 16 + static_cast<size_t>(len) / 32 + 4;
+    return (static_cast<size_t>(len) + 3 * events + 1 + 6) / 7 * 8 + 16;
+}
 __host__ __device__ inline int banded_stream_layout(int len, int k, const char *row, unsigned char *dst)
 {
     const int last = (len <= 64) ? len : ((len - k > 64) ? len - k : 64);
@@ -77,38 +90,50 @@ __host__ __device__ inline int banded_stream_layout(int len, int k, const char *
         if (dst) dst[pos] = b;
         pos++;
         if (++slot == 7) {
-            if (dst) dst[pos] = kCodeRefill;
+            if (dst) dst[pos] = kBandedRefill;
             pos++;
             slot = 0;
         }
     };
     auto put_event = [&](int bits) {
         if (slot == 6) {  // one payload byte left: close the window
-            if (dst) { dst[pos] = kCodeRefill; dst[pos + 1] = kCodeEnd; }
+            if (dst) { dst[pos] = kBandedRefill; dst[pos + 1] = kBandedEnd; }
             pos += 2;
             slot = 0;
         }
-        put(7);
+        put(kBandedEvent);
         put(static_cast<unsigned char>(bits));
     };
-    for (int r = 0; r < len; r++) {
-        if (r == k) pending |= 1;
-        if (r > 0 && (r & 31) == 0) pending |= 2;
+    auto code_of = [&](int r) -> int {
+        if (!row) return 0;
+        const int c = static_cast<unsigned char>(row[r]);
+        return c > 4 ? 0 : c;
+    };
+    // events due before row r starts / after `done` rows are complete
+    auto before = [&](int r) { return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0); };
+    auto after = [&](int done) {
+        return (done > k && done <= last && ((done & 15) == 0 || done == last)) ? (4 | (done == last ? 8 : 0)) : 0;
+    };
+    for (int r = 0; r < len;) {
+        pending |= before(r);
         if (pending) { put_event(pending); pending = 0; }
-        unsigned char code = 0;
-        if (row) { code = static_cast<unsigned char>(row[r]); if (code > 4) code = 0; }
-        put(code);
-        const int done = r + 1;
-        if (done > k && done <= last && ((done & 15) == 0 || done == last)) pending |= 4 | (done == last ? 8 : 0);
+        if (r + 1 < len && !after(r + 1) && !before(r + 1)) {   // nothing between rows r and r+1
+            put(static_cast<unsigned char>(5 * code_of(r) + code_of(r + 1)));
+            r += 2;
+        } else {
+            put(static_cast<unsigned char>(kBandedSingle + code_of(r)));
+            r += 1;
+        }
+        pending |= after(r);
     }
     if (pending) put_event(pending);
-    put(kCodeEnd);
+    put(kBandedEnd);
     while (pos & 7) {  // pad the last window with END
-        if (dst) dst[pos] = kCodeEnd;
+        if (dst) dst[pos] = kBandedEnd;
         pos++;
     }
     for (int i = 0; i < 8; i++) {  // spare window: the loop fetches one window ahead
-        if (dst) dst[pos] = kCodeEnd;
+        if (dst) dst[pos] = kBandedEnd;
         pos++;
     }
     return pos;

@@ -298,8 +298,8 @@ size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queri
         const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
         return blocked > in_memory ? blocked : in_memory;
     }
-    if (algo == BGSA_ALGO_BANDED)  // event tokens make the stream longer; k = 1 is the longest
-        return static_cast<size_t>(banded_stream_layout(ref_len, 1, nullptr, nullptr) + 16) * n_queries;
+    if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k, which this query does not know
+        return banded_stream_bound(ref_len) * n_queries;
     return stream_stride(ref_len) * static_cast<size_t>(n_queries);
 }
 

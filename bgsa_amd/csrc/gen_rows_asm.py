@@ -179,7 +179,19 @@ def gen_banded_function(wide: bool) -> str:
         return reg
 
     def disp() -> list[str]:
-        return dispatch()
+        # token codes 0..32 (bgsa_common.h: banded_stream_layout); slot stride = a two-row body
+        return [
+            f"s_and_b32 {S_C}, {S_WIN_LO}, 0x3f",
+            f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
+            f"s_mul_i32 {S_C}, {S_C}, (L_body1_%= - L_body0_%=)",
+            f"s_add_u32 {S_PC_LO}, {S_BASE_LO}, {S_C}",
+            f"s_addc_u32 {S_PC_HI}, {S_BASE_HI}, 0",
+            f"s_setpc_b64 {S_PC}",
+        ]
+
+    def pad(slot: int) -> str:
+        """s_nop filler (never executed) up to the common slot stride."""
+        return f".fill ((L_body1_%= - L_body0_%=) - (L_end{slot}_%= - L_body{slot}_%=)) / 4, 4, 0xbf800000"
 
     asm = [
         f"s_mov_b64 {S_PTR}, %[qp]",
@@ -201,15 +213,26 @@ def gen_banded_function(wide: bool) -> str:
         "s_waitcnt lgkmcnt(0)",
     ]
     asm += disp()
-    for c in range(5):
-        asm.append(f"L_body{c}_%=:")
+    for a in range(5):          # slots 0..24: two rows per token (the dispatch is the loop's scalar bottleneck)
+        for b2 in range(5):
+            asm.append(f"L_body{5 * a + b2}_%=:")
+            asm += body.emit_asm(reg_for(a), a)
+            asm.append(f"s_add_u32 {S_SH}, {S_SH}, 1")
+            asm += body.emit_asm(reg_for(b2), b2)
+            asm.append(f"s_add_u32 {S_SH}, {S_SH}, 1")
+            asm += disp()
+    for c in range(5):          # slots 25..29: one row
+        asm.append(f"L_body{25 + c}_%=:")
         asm += body.emit_asm(reg_for(c), c)
         asm.append(f"s_add_u32 {S_SH}, {S_SH}, 1")
         asm += disp()
-    asm.append("L_body5_%=:")  # END
+        asm.append(f"L_end{25 + c}_%=:")
+        asm.append(pad(25 + c))
+    asm.append("L_body30_%=:")  # END
     asm.append("s_branch L_done_%=")
-    asm.append(".fill ((L_body1_%= - L_body0_%=) - 4) / 4, 4, 0xbf800000")
-    asm.append("L_body6_%=:")  # REFILL
+    asm.append("L_end30_%=:")
+    asm.append(pad(30))
+    asm.append("L_body31_%=:")  # REFILL
     asm += [
         f"s_sub_u32 {S_LEFT}, {S_LEFT}, 1",
         "s_cbranch_scc1 L_done_%=",
@@ -220,9 +243,9 @@ def gen_banded_function(wide: bool) -> str:
         f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
     ]
     asm += disp()
-    asm.append("L_refill_end_%=:")
-    asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
-    asm.append("L_body7_%=:")  # EVENT <arg>
+    asm.append("L_end31_%=:")
+    asm.append(pad(31))
+    asm.append("L_body32_%=:")  # EVENT <arg>
     asm += [
         f"s_and_b32 {S_ARG}, {S_WIN_LO}, 0xff",
         f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",

@@ -566,6 +566,52 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
     return out
 
 
+BANDED_SINGLE, BANDED_END, BANDED_REFILL, BANDED_EVENT = 25, 30, 31, 32
+
+
+def banded_stream_bytes(length: int, k: int, codes) -> list:
+    """The packed banded stream, byte for byte as bgsa_common.h: banded_stream_layout() writes it:
+    banded_tokens() with two consecutive rows folded into one token (5*a + b) wherever no event sits
+    between them, one-row tokens 25 + c otherwise, EVENT = {32, bits}, 7 payload bytes + REFILL per
+    8-byte window, a two-byte token never split across windows, END padding and one spare END window."""
+    out, slot = [], 0
+
+    def put(b):
+        nonlocal slot
+        out.append(b)
+        slot += 1
+        if slot == 7:
+            out.append(BANDED_REFILL)
+            slot = 0
+
+    def put_event(bits):
+        nonlocal slot
+        if slot == 6:
+            out.extend([BANDED_REFILL, BANDED_END])
+            slot = 0
+        put(BANDED_EVENT)
+        put(bits)
+
+    toks = banded_tokens(length, k)
+    i = 0
+    while i < len(toks):
+        kind, val = toks[i]
+        if kind == "event":
+            put_event(val)
+            i += 1
+        elif i + 1 < len(toks) and toks[i + 1][0] == "row":
+            put(5 * int(codes[val]) + int(codes[toks[i + 1][1]]))
+            i += 2
+        else:
+            put(BANDED_SINGLE + int(codes[val]))
+            i += 1
+    put(BANDED_END)
+    while len(out) % 8:
+        out.append(BANDED_END)
+    out.extend([BANDED_END] * 8)
+    return out
+
+
 def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool | None = None) -> np.ndarray:
     """Whole banded pipeline on the CPU with the shipped row body: Mext preprocess, token
     stream, events, final band walk.  Returns int8 results like the kernel.  wide = the 64-bit

@@ -206,11 +206,13 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
                                  void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Introspection (host only, no GPU): the packed code stream the kernels walk for one mapped query
- * row (codes 0..4 = row of that character class, 5 = END, 6 = REFILL, 7 = EVENT + argument byte;
- * 8-byte windows).  Writes at most `cap` bytes to dst (may be NULL) and returns the stream length
- * in bytes.  For BGSA_ALGO_BANDED the stream carries the event tokens for threshold k; for
- * BGSA_ALGO_MYERS, k < 0 selects the stream of the column-block kernel (subjects > 1024 bp: a
- * CARRY token, code 7, in front of every 32nd row). */
+ * row, 8-byte windows of 7 tokens + REFILL.  Myers / BitPAl: codes 0..4 = row of that character
+ * class, 5 = END, 6 = REFILL; for BGSA_ALGO_MYERS, k < 0 selects the stream of the column-block
+ * kernel (subjects > 1024 bp: a CARRY token, code 7, in front of every 32nd row).
+ * BGSA_ALGO_BANDED (threshold k): 0..24 = two rows of classes a, b as 5*a + b, 25..29 = one row,
+ * 30 = END, 31 = REFILL, 32 = EVENT + argument byte (1 reset the error count, 2 advance the match
+ * words, 4 test the limit, 8 latch the reject mask).
+ * Writes at most `cap` bytes to dst (may be NULL) and returns the stream length in bytes. */
 int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, unsigned char *dst, int cap);
 
 /* Name of the kernel the previous call would launch for these shapes (for profiles/bench). */

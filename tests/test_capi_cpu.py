@@ -107,39 +107,30 @@ def test_host_handle_reads_layout_banded(L, oracle):
         assert int(np.bitwise_count(peq[0, :, :, s]).sum()) == 150
 
 
-def _decode_stream(raw):
-    """Walk a packed stream the way the row loop does: returns the token list."""
+def _decode_banded_stream(raw):
+    """Walk a packed banded stream the way the row loop does: returns the (row | event) sequence."""
     tokens, pos, win = [], 0, 0
     while True:
         base = 8 * win
-        code = raw[base + pos]
+        code = int(raw[base + pos])
         pos += 1
-        if code <= 4:
-            tokens.append(("row", int(code)))
-        elif code == 5:
+        if code < 25:                       # two rows
+            tokens += [("row", code // 5), ("row", code % 5)]
+        elif code < 30:                     # one row
+            tokens.append(("row", code - 25))
+        elif code == 30:
             return tokens
-        elif code == 6:
+        elif code == 31:
             win, pos = win + 1, 0
         else:
+            assert code == 32
             tokens.append(("event", int(raw[base + pos])))
             pos += 1
         assert pos <= 8
 
 
-@pytest.mark.parametrize("qlen", [1, 6, 7, 8, 14, 150, 151, 1000])
-def test_plain_query_stream(L, qlen):
-    rng = np.random.default_rng(qlen)
-    row = rng.integers(0, 5, qlen).astype(np.uint8)
-    n = L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, 0, None, 0)
-    assert n == (qlen // 7 + 2) * 8
-    buf = np.full(n, 0xEE, dtype=np.uint8)
-    assert L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, 0, buf.ctypes.data, n) == n
-    assert [t for t in _decode_stream(buf)] == [("row", int(c)) for c in row]
-    assert (buf[-8:] == 5).all()                       # the spare window the loop may prefetch
-    assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_MYERS, qlen, 150, 3) == 3 * n
-
-
-@pytest.mark.parametrize("length,k", [(150, 8), (150, 1), (150, 15), (64, 8), (65, 3), (33, 2), (1000, 8)])
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 1), (150, 15), (150, 16), (150, 31), (64, 8), (65, 3), (33, 2),
+                                      (1000, 8), (1000, 7), (97, 9), (257, 30)])
 def test_banded_query_stream_matches_the_token_model(L, length, k):
     import sys
     from pathlib import Path
@@ -150,10 +141,23 @@ def test_banded_query_stream_matches_the_token_model(L, length, k):
     n = L.bgsa_hip_query_stream(B.ALGO_BANDED, row.ctypes.data, length, k, None, 0)
     buf = np.full(n, 0xEE, dtype=np.uint8)
     assert L.bgsa_hip_query_stream(B.ALGO_BANDED, row.ctypes.data, length, k, buf.ctypes.data, n) == n
+    # byte for byte the Python model of the layout ...
+    assert buf.tolist() == R.banded_stream_bytes(length, k, row)
+    # ... which decodes to exactly the row / event sequence the simulator executes
     want = [("row", int(row[v])) if kind == "row" else ("event", v) for kind, v in R.banded_tokens(length, k)]
-    assert _decode_stream(buf) == want
-    assert n % 8 == 0 and (buf[-8:] == 5).all()
+    assert _decode_banded_stream(buf) == want
+    assert n % 8 == 0 and (buf[-8:] == 30).all()
+    assert (buf < 25).sum() >= length // 2 - 2 * (length // 16 + 3)      # most rows travel in pairs
     assert B.lib().bgsa_hip_workspace_bytes(B.ALGO_BANDED, length, length, 2) >= 2 * n
+
+
+def test_banded_workspace_bound_covers_every_threshold(L):
+    for length in (33, 64, 65, 100, 150, 151, 255, 1000, 1001):
+        bound = B.lib().bgsa_hip_workspace_bytes(B.ALGO_BANDED, length, length, 1)
+        row = np.zeros(length, dtype=np.uint8)
+        for k in range(1, 32):
+            if 2 * k + 1 < length:
+                assert 0 < L.bgsa_hip_query_stream(B.ALGO_BANDED, row.ctypes.data, length, k, None, 0) <= bound
 
 
 @pytest.mark.parametrize("qlen", [1, 31, 32, 33, 64, 100, 1000])
