@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -419,6 +420,10 @@ void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_
     (void)chunk_read_num;  // CPU cache-blocking knob (cal_cpu.c:266); the GPU grid tiles itself
     (void)dvdh_bit_mem;    // per-thread scratch of the CPU kernels; state lives in VGPRs here
     if (ref_end <= ref_start || read_count <= 0) return;
+    // The reference calls align_<arch> from its OpenMP workers (cal_cpu.c:63-84): the staging buffers
+    // below are shared, so concurrent callers take turns.
+    static std::mutex seam;
+    std::lock_guard<std::mutex> turn(seam);
     const size_t content_bytes = static_cast<size_t>(ref_count) * (ref_len + 1);
     const size_t peq_bytes = bgsa_hip_group_words(g_algo, word_num, threshold) * sizeof(hip_read_t) *
                              (static_cast<size_t>(read_count) / HIP_V_NUM);

@@ -169,3 +169,47 @@ def test_cli_semiglobal_myers(tmp_path, oracle):
     got, _ = _run_cli(tmp_path, g, extra_args=["-s"])
     assert np.array_equal(got, oracle.dp_edit_semiglobal(q, s))
     assert (got[np.arange(10) % 5, np.arange(10)] == 0).all()     # exact windows of the query
+
+
+# ---- the drop-in boundary end to end: the REFERENCE's own main.c / file.c / thread.c / cal_cpu.c,
+# unmodified, compiled against libbgsa_hip.so in place of its global.c + align_core.c
+# (oracle/Makefile: _ref/original_hip, examples/BGSA_HIP/config_hip.h) -------------------------------------
+REF_HIP = ROOT / "oracle" / "_ref" / "original_hip"
+
+
+def _run_reference_host(tmp_path, g, binary, threads=4, env_extra=None):
+    (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
+    (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
+    env = dict(os.environ, **(env_extra or {}))
+    p = subprocess.run([str(REF_HIP / binary), "-q", "query.txt", "-d", "subject.txt", "-f", "result.txt", "-N", str(threads)],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    conv = ROOT / "oracle" / "_ref" / "original_cpu" / "convert"
+    subprocess.run([str(conv), "-r", "result.txt", "-o", "scores.txt"], cwd=tmp_path, check=True, capture_output=True)
+    flat = np.loadtxt(tmp_path / "scores.txt", dtype=np.int64, ndmin=1)
+    return flat.reshape(g["queries"].shape[0], g["subjects"].shape[0]), p.stdout
+
+
+@pytest.mark.parametrize("name,binary", [("f1_myers_150", "aligner"), ("f6_myers_ns100", "aligner"),
+                                         ("f9_myers_140x150", "aligner"), ("f7_bitpal_150", "aligner_bitpal")])
+def test_reference_host_pipeline_on_the_gpu_library(tmp_path, name, binary):
+    if not (REF_HIP / binary).exists():
+        pytest.skip("oracle/_ref/original_hip not built (needs /root/reference at build time)")
+    g = load_golden(name)
+    got, report = _run_reference_host(tmp_path, g, binary)
+    assert np.array_equal(got, g["scores"])          # the reference's scores, through its own host code
+    assert "GCUPS" in report
+
+
+def test_reference_host_pipeline_other_scores(tmp_path, oracle):
+    sets = [x for x in B.score_sets() if x != (2, -3, -5)]
+    if not (REF_HIP / "aligner_bitpal").exists() or not sets:
+        pytest.skip("oracle/_ref/original_hip not built or no extra score set")
+    m, x, gp = sets[0]
+    q = oracle.gen_reads(71, 6, 150)
+    s = oracle.gen_reads(72, 200, 150)
+    s[:6] = oracle.mutate(q, np.arange(6), 73)
+    g = {"queries": q, "subjects": s}
+    got, report = _run_reference_host(tmp_path, g, "aligner_bitpal", env_extra={"BGSA_HIP_SCORES": f"{m},{x},{gp}"})
+    assert np.array_equal(got, oracle.dp_nw(q, s, m, x, gp))
+    assert f"score is {m}, {x}, {gp}" in report
