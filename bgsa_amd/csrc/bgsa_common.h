@@ -225,10 +225,10 @@ inline int blocked_workgroups()
     }();
     return n;
 }
-#define kBlockedBlocks (::bgsa::blocked_workgroups())
+
 inline size_t blocked_carry_bytes(int ref_len, int n_chains)
 {
-    return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * kBlockedBlocks;
+    return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * blocked_workgroups();
 }
 size_t long_state_bytes(int algo, int word_num);
 int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,

@@ -438,7 +438,7 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     const size_t stream_bytes = (static_cast<size_t>(stride) * nq + 255) & ~static_cast<size_t>(255);
     if (int rc = launch_pack_blocked(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
     uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
-    hipLaunchKernelGGL((myers_blocked_kernel<NW>), dim3(kBlockedBlocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((myers_blocked_kernel<NW>), dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
                        stride, n_blocks);
