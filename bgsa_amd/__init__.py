@@ -169,6 +169,7 @@ class DeviceAligner:
     def __init__(self, algo: int = ALGO_MYERS, device: str = "cuda:0", k: int = 0, scores=None,
                  semi_global: bool = False):
         """scores: (match, mismatch, gap) for ALGO_BITPAL; None = the reference's 2 / -3 / -5.
+        For ALGO_MYERS (0, 1, 1) reports +distance (generator -m 1) instead of -distance.
         semi_global (generator -s): ALGO_BITPAL — query end to end, free subject overhangs;
         ALGO_MYERS — subject end to end inside the query (the generator's orientations differ)."""
         import torch
@@ -176,8 +177,8 @@ class DeviceAligner:
         self.algo, self.k = algo, int(k)
         self.scores = tuple(int(x) for x in scores) if scores is not None else None
         self.semi_global = bool(semi_global)
-        if self.scores is not None and algo != ALGO_BITPAL:
-            raise BgsaHipError("scores only apply to ALGO_BITPAL")
+        if self.scores is not None and algo != ALGO_BITPAL and not (algo == ALGO_MYERS and self.scores in ((0, 1, 1), (0, -1, -1))):
+            raise BgsaHipError("scores apply to ALGO_BITPAL; ALGO_MYERS only knows (0, -1, -1) and (0, 1, 1) = +distance")
         if self.semi_global and algo == ALGO_BANDED:
             raise BgsaHipError("semi_global is not defined for the banded filter")
         self.device = torch.device(device)
@@ -243,7 +244,9 @@ class DeviceAligner:
         # the score set and the alignment mode are process-global state of the C ABI (the reference's ints)
         if self.algo == ALGO_BITPAL:
             check(lib().bgsa_hip_select_scores(*(self.scores or (2, -3, -5))), "select_scores")
-        elif lib().bgsa_hip_current_algorithm() != self.algo:
+        elif self.algo == ALGO_MYERS and self.scores == (0, 1, 1):
+            check(lib().bgsa_hip_select_scores(0, 1, 1), "select_scores")       # generator -m 1: +distance
+        else:   # also resets the score ints a BitPAl / +distance selection left behind
             check(lib().bgsa_hip_select_algorithm(self.algo), "select_algorithm")
         check(lib().bgsa_hip_select_alignment(1 if self.semi_global else 0), "select_alignment")
 

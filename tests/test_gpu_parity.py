@@ -416,18 +416,11 @@ def test_scores_with_common_factor(oracle, qlen, slen):
 def test_myers_positive_distance(oracle, slen):
     q = oracle.gen_reads(43, 4, 150)
     s = _related(oracle, q, 130, slen, 44)
-    L = B.lib()
-    a = B.DeviceAligner(B.ALGO_MYERS)
-    a.set_queries(q)
-    a.set_subjects(s)
-    neg = a.score()[:, :130].cpu().numpy()
+    neg = B.align_all_pairs(q, s, algo=B.ALGO_MYERS)
     assert np.array_equal(neg, oracle.myers64(q, s))
-    assert L.bgsa_hip_select_scores(0, 1, 1) == 0               # generator option -m 1
-    try:
-        pos = a.score()[:, :130].cpu().numpy()
-    finally:
-        assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
+    pos = B.align_all_pairs(q, s, algo=B.ALGO_MYERS, scores=(0, 1, 1))      # generator option -m 1
     assert np.array_equal(pos, -neg) and (pos >= 0).all()
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), neg)   # and the sign does not stick
     assert np.array_equal(pos, -oracle.dp_edit(q, s).astype(np.int32))   # dp_edit follows the reference sign: -distance
 
 
