@@ -1081,7 +1081,7 @@ def bitpal_block_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT):
 
 def bitpal_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     """For the default scores this is the packed kernel of original/BGSA_AVX2/align_core.c:183-428
-    (same five planes, same two's complement of -(dH + 5)) at 76 fast-class VALU per word."""
+    (same five planes, same two's complement of -(dH + 5)) at 75 fast-class VALU per word."""
     return bitpal_scores_body(nw, sc)
 
 
