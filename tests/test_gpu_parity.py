@@ -445,3 +445,20 @@ def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
 def test_myers_semiglobal_beyond_1024_is_refused(oracle):
     with pytest.raises(B.BgsaHipError, match="1024"):
         B.align_all_pairs(oracle.gen_reads(1, 2, 100), oracle.gen_reads(2, 64, 1100), algo=B.ALGO_MYERS, semi_global=True)
+
+
+# ---- BASELINE.json configs[0] on the GPU: 1k x 1k x 150 bp against the reference binary run live ------
+def test_config0_hip_matches_live_reference(oracle):
+    if not oracle.have_reference("original_cpu"):
+        pytest.skip("reference binaries not built (oracle/_ref)")
+    q = oracle.gen_reads(0xC0, 1000, 150)
+    s = oracle.gen_reads(0xC1, 1000, 150)
+    s[:100] = oracle.mutate(q[:100], np.arange(100) % 13, 0xC2)
+    ref, _ = oracle.run_reference("original_cpu", q, s, threads=8)
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), ref)
+    if oracle.have_reference("original_avx2"):
+        ref_bp, _ = oracle.run_reference("original_avx2", q[:200], s, threads=8)
+        assert np.array_equal(B.align_all_pairs(q[:200], s, algo=B.ALGO_BITPAL), ref_bp)
+    if oracle.have_reference("banded_cpu"):
+        ref_bd, _ = oracle.run_reference("banded_cpu", q[:200], s, threads=8, k=8)
+        assert np.array_equal(B.align_all_pairs(q[:200], s, algo=B.ALGO_BANDED, k=8), ref_bd)
