@@ -462,3 +462,69 @@ def test_config0_hip_matches_live_reference(oracle):
     if oracle.have_reference("banded_cpu"):
         ref_bd, _ = oracle.run_reference("banded_cpu", q[:200], s, threads=8, k=8)
         assert np.array_equal(B.align_all_pairs(q[:200], s, algo=B.ALGO_BANDED, k=8), ref_bd)
+
+
+# ---- BASELINE.json configs 1-3 at their FULL size (10k queries x 1M subjects x 150 bp = 1e10 pairs, 20 GB of
+# scores): far beyond the CPU oracle, so checked through properties that do not depend on size ----------
+@pytest.mark.parametrize("algo,k", [(B.ALGO_MYERS, 0), (B.ALGO_BANDED, 8), (B.ALGO_BITPAL, 0)])
+def test_full_baseline_size_properties(oracle, algo, k):
+    import torch
+    dev = torch.device("cuda:0")
+    nq, ns, length = 10_000, 1_000_000, 150
+    ns_pad = (ns + 63) // 64 * 64
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + algo)
+    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    q_rows = letters[torch.randint(0, 4, (nq, length), generator=gen, device=dev)]
+    s_rows = torch.full((ns_pad, length + 1), ord("\n"), dtype=torch.uint8, device=dev)
+    s_rows[:, :length] = ord("N")
+    s_rows[:ns, :length] = letters[torch.randint(0, 4, (ns, length), generator=gen, device=dev)]
+    # plant query i as subject planted[i]; duplicate 4096 other subjects far away (other group, lane, block)
+    planted = torch.randperm(ns, generator=gen, device=dev)[:nq]
+    s_rows[planted, :length] = q_rows
+    cand = torch.randperm(ns, generator=gen, device=dev)[:8192]
+    is_planted = torch.zeros(ns, dtype=torch.bool, device=dev)
+    is_planted[planted] = True
+    src = cand[:4096]
+    dst = (src + ns // 2 + 37) % ns
+    ok = ~is_planted[dst] & ~is_planted[src]
+    src, dst = src[ok], dst[ok]
+    taken = torch.zeros(ns, dtype=torch.bool, device=dev)
+    taken[src] = True
+    keep = ~taken[dst]
+    src, dst = src[keep], dst[keep]
+    s_rows[dst] = s_rows[src]
+
+    a = B.DeviceAligner(algo, "cuda:0", k)
+    q_host = q_rows.cpu().numpy()
+    a.set_queries(q_host)
+    a.set_subject_rows_device(s_rows.reshape(-1), ns_pad, length, qlen=length)
+    scores = a.score()
+    torch.cuda.synchronize()
+    assert scores.shape == (nq, ns_pad)
+    idx = torch.arange(nq, device=dev)
+    exact = {B.ALGO_MYERS: 0, B.ALGO_BANDED: 0, B.ALGO_BITPAL: 2 * length}[algo]
+    assert bool((scores[idx, planted] == exact).all())                       # identical pair
+    assert bool((scores[:, src] == scores[:, dst]).all())                     # same subject, other place, same score
+    lo, hi = {B.ALGO_MYERS: (-length, 0), B.ALGO_BANDED: (0, 127), B.ALGO_BITPAL: (-5 * 2 * length, 2 * length)}[algo]
+    n_passed = 0
+    for q0 in range(0, nq, 1000):        # reductions in blocks of 1e9 elements
+        blk = scores[q0:q0 + 1000, :ns]
+        assert int(blk.min()) >= lo and int(blk.max()) <= hi
+        if algo == B.ALGO_BANDED:    # the filter: random pairs are rejected, and what passes is within the band
+            passed = blk != 127
+            n_passed += int(passed.sum())
+            assert not bool((passed & (blk > 2 * k + 1)).any())
+    if algo == B.ALGO_BANDED:
+        assert nq <= n_passed < nq * 50
+    # a random sample of the 1e10 pairs against the oracle
+    rng = np.random.default_rng(99 + algo)
+    qi, sj = rng.integers(0, nq, 600), rng.integers(0, ns, 600)
+    got = scores[torch.from_numpy(qi).to(dev), torch.from_numpy(sj).to(dev)].cpu().numpy()
+    sub = s_rows[torch.from_numpy(sj).to(dev), :length].cpu().numpy()
+    fn = {B.ALGO_MYERS: oracle.myers64, B.ALGO_BITPAL: oracle.bitpal, B.ALGO_BANDED: lambda x, y: oracle.banded64(x, y, k)}[algo]
+    want = np.array([fn(q_host[i:i + 1], sub[n:n + 1])[0, 0] for n, i in enumerate(qi)])
+    assert np.array_equal(got, want)
+    # the padding reads never alias a real subject: all-'N' against ACGT is all mismatches
+    if algo == B.ALGO_MYERS:
+        assert bool((scores[:, ns:] == -length).all())
