@@ -464,13 +464,15 @@ def test_config0_hip_matches_live_reference(oracle):
         assert np.array_equal(B.align_all_pairs(q[:200], s, algo=B.ALGO_BANDED, k=8), ref_bd)
 
 
-# ---- BASELINE.json configs 1-3 at their FULL size (10k queries x 1M subjects x 150 bp = 1e10 pairs, 20 GB of
-# scores): far beyond the CPU oracle, so checked through properties that do not depend on size ----------
-@pytest.mark.parametrize("algo,k", [(B.ALGO_MYERS, 0), (B.ALGO_BANDED, 8), (B.ALGO_BITPAL, 0)])
-def test_full_baseline_size_properties(oracle, algo, k):
+# ---- BASELINE.json configs 1-4 at their FULL size (10k queries x 1M subjects x 150 bp = 1e10 pairs, 20 GB of
+# scores; 1k x 125k x 1000 bp per GPU): far beyond the CPU oracle, so checked through properties that do not depend on size ----------
+@pytest.mark.parametrize("algo,k,nq,ns,length", [(B.ALGO_MYERS, 0, 10_000, 1_000_000, 150),
+                                                 (B.ALGO_BANDED, 8, 10_000, 1_000_000, 150),
+                                                 (B.ALGO_BITPAL, 0, 10_000, 1_000_000, 150),
+                                                 (B.ALGO_MYERS, 0, 1_000, 125_000, 1000)])   # configs[4], one GPU's shard
+def test_full_baseline_size_properties(oracle, algo, k, nq, ns, length):
     import torch
     dev = torch.device("cuda:0")
-    nq, ns, length = 10_000, 1_000_000, 150
     ns_pad = (ns + 63) // 64 * 64
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + algo)
@@ -519,7 +521,8 @@ def test_full_baseline_size_properties(oracle, algo, k):
         assert nq <= n_passed < nq * 50
     # a random sample of the 1e10 pairs against the oracle
     rng = np.random.default_rng(99 + algo)
-    qi, sj = rng.integers(0, nq, 600), rng.integers(0, ns, 600)
+    n_sample = 600 if length <= 256 else 150
+    qi, sj = rng.integers(0, nq, n_sample), rng.integers(0, ns, n_sample)
     got = scores[torch.from_numpy(qi).to(dev), torch.from_numpy(sj).to(dev)].cpu().numpy()
     sub = s_rows[torch.from_numpy(sj).to(dev), :length].cpu().numpy()
     fn = {B.ALGO_MYERS: oracle.myers64, B.ALGO_BITPAL: oracle.bitpal, B.ALGO_BANDED: lambda x, y: oracle.banded64(x, y, k)}[algo]
