@@ -101,6 +101,8 @@ int bgsa_hip_current_algorithm(void);
  * bgsa_hip_select_scores(0, 1, 1) is the generator's `-m 1`: BGSA_ALGO_MYERS reporting +distance
  * instead of -distance (the same ints written directly while Myers is selected do the same). */
 int bgsa_hip_select_scores(int match, int mismatch, int gap);
+int bgsa_hip_score_set_count(void);
+int bgsa_hip_score_set(int index, int *match, int *mismatch, int *gap, int *valu_per_word);
 
 /* Global (default) or semi-global scoring — the generator's `-s` option (Configuration.isSemiGlobal).
  * The two generators orient it differently, and so does this library:
@@ -115,8 +117,6 @@ int bgsa_hip_select_scores(int match, int mismatch, int gap);
 enum { BGSA_ALIGN_GLOBAL = 0, BGSA_ALIGN_SEMIGLOBAL = 1 };
 int bgsa_hip_select_alignment(int mode);
 int bgsa_hip_current_alignment(void);
-int bgsa_hip_score_set_count(void);
-int bgsa_hip_score_set(int index, int *match, int *mismatch, int *gap, int *valu_per_word);
 
 /* word_num for the selected algorithm (what cal_<arch>.c computes at cal_cpu.c:252-256, banded
  * cal_cpu.c:253-254). */
@@ -125,9 +125,10 @@ int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k);
 size_t bgsa_hip_group_words(int algo, int word_num, int k);
 
 /* ---- BGSA backend surface (host buffers) ---------------------------------------------------
- * These three share one grow-only device workspace inside the library: call them from one thread
- * at a time (the reference's pipeline calls its seams from the main thread only, cal_cpu.c:363-401).
- * bgsa_hip_release_workspace() frees that workspace. */
+ * align_hip / hip_cal_align_score share one grow-only device workspace inside the library and take
+ * turns on it: they may be called from several host threads, as the reference's OpenMP loop calls
+ * align_<arch> (cal_cpu.c:63-84), but the calls are serialised.  bgsa_hip_release_workspace() frees
+ * that workspace. */
 
 /* ASCII rows -> Peq blocks, layout [group][char 0..4][word][lane 0..63]
  * (replaces cpu_handle_reads, reference original/BGSA_CPU/global.c:25-70; for BGSA_ALGO_BANDED
@@ -190,8 +191,9 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream);
 
 /* Scratch the hot path needs for n_queries queries of ref_len characters against subjects of
  * read_len characters: the queries re-packed into 8-byte-aligned code streams the kernels fetch
- * through the scalar cache, or, for subjects too long for the register-resident kernels (Myers
- * > 1024 bp, BitPAl > 256 bp), the per-wave DP state. */
+ * through the scalar cache, plus, for subjects too long for the register-resident kernels (Myers
+ * > 1024 bp, BitPAl beyond the plain widths of the selected score set, > 256 bp for 2/-3/-5), the
+ * per-wave carry words of the column-block kernels.  Depends on the selected score set. */
 size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries);
 
 /* The hot path.  d_content = mapped query rows, stride ref_len+1 (reference cal_cpu.c:78);
