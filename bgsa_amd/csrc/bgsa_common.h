@@ -63,6 +63,36 @@ __host__ __device__ inline unsigned long long plain_stream_window(const char *ro
 int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
                         void *d_streams, hipStream_t stream);
 
+// Two-rows-per-token stream of the short-subject Myers kernels (<= 64 bp): token t covers query
+// characters 2t and 2t+1 as 5*a + b (0..24), an odd last character travels alone as 25 + c; 30 = END,
+// 31 = REFILL; 7 tokens + REFILL per window, one spare all-END window, as in the plain stream.
+constexpr int kPairSingle = 25, kPairEnd = 30, kPairRefill = 31;
+inline int pair_stream_windows(int ref_len) { return ((ref_len + 1) / 2) / 7 + 1; }
+inline size_t pair_stream_stride(int ref_len) { return static_cast<size_t>(pair_stream_windows(ref_len) + 1) * 8; }
+__host__ __device__ inline unsigned long long pair_stream_window(const char *row, int ref_len, int i)
+{
+    const int n_tokens = (ref_len + 1) / 2;
+    const int n_windows = n_tokens / 7 + 1;
+    auto code_of = [&](int r) -> unsigned {
+        const unsigned c = static_cast<unsigned char>(row[r]);
+        return c > 4 ? 0u : c;   // as plain_stream_window: out-of-alphabet bytes behave as 'A'
+    };
+    unsigned long long win = 0;
+    for (int j = 0; j < 8; j++) {
+        unsigned code = kPairEnd;
+        if (i < n_windows) {
+            const int t = 7 * i + j;
+            if (j == 7) code = (i < n_windows - 1) ? kPairRefill : kPairEnd;
+            else if (t < n_tokens)
+                code = (2 * t + 1 < ref_len) ? 5u * code_of(2 * t) + code_of(2 * t + 1) : kPairSingle + code_of(2 * t);
+        }
+        win |= static_cast<unsigned long long>(code) << (8 * j);
+    }
+    return win;
+}
+int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, int ref_end,
+                            void *d_streams, hipStream_t stream);
+
 // Banded stream (rows_ir.py: banded_tokens / banded_stream_codes).  The banded row is short (12 VALU),
 // so the scalar work of the threaded-code dispatch is what its loop waits for; one token therefore
 // carries TWO consecutive rows whenever nothing has to happen between them:
@@ -74,7 +104,7 @@ int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int r
 // Writes the stream when dst != nullptr (row = mapped query characters); returns its length in bytes
 // including the spare window.  The same routine sizes the workspace on the host and fills it on the
 // device.
-constexpr int kBandedSingle = 25, kBandedEnd = 30, kBandedRefill = 31, kBandedEvent = 32;
+constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill = kPairRefill, kBandedEvent = 32;
 // Upper bound of banded_stream_layout(len, k) over every k (sizes the workspace, which does not know k):
 // all rows as one-row tokens, every event two bytes plus one byte lost to an early window close.
 inline size_t banded_stream_bound(int len)

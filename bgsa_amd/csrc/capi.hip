@@ -373,7 +373,16 @@ int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, 
         if (dst && cap >= n) banded_stream_layout(ref_len, k, mapped_row, dst);
         return n;
     }
-    if (algo == BGSA_ALGO_MYERS && k < 0) {  // k < 0: the column-block stream (subjects > 1024 bp)
+    if (algo == BGSA_ALGO_MYERS && k == -2) {  // the two-rows-per-token stream (subjects <= 64 bp)
+        const int n = static_cast<int>(pair_stream_stride(ref_len));
+        if (dst && cap >= n)
+            for (int i = 0; i <= pair_stream_windows(ref_len); i++) {
+                const unsigned long long w = pair_stream_window(mapped_row, ref_len, i);
+                memcpy(dst + 8 * i, &w, 8);
+            }
+        return n;
+    }
+    if (algo == BGSA_ALGO_MYERS && k < 0) {  // k = -1: the column-block stream (subjects > 1024 bp)
         const int n = blocked_stream_layout(ref_len, nullptr, nullptr);
         if (dst && cap >= n) blocked_stream_layout(ref_len, mapped_row, dst);
         return n;

@@ -32,6 +32,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 import rows_ir as R  # noqa: E402
 
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8]
+MYERS_PAIR_NW = [1, 2]  # two rows per stream token: the 10-20 VALU row cannot hide the scalar dispatch
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word
 MYERS_BLOCK_NW = [12, 14, 16, 18, 20, 22, 24, 26, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
 BITPAL_VGPR_BUDGET = 224        # state + masks + temporaries a plain BitPAl kernel may hold
@@ -132,6 +133,101 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
 template <>
 __device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
                                                    {masks_param},
+                                                   const unsigned long long stream,
+                                                   const int n_windows)
+{{
+    uint32_t tmp[{max(n_slots, 1)}];
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+}}
+"""
+
+
+def gen_pair_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n_eq: int) -> str:
+    """Row loop for bodies too short to hide the scalar dispatch (Myers on short subjects: 10-20 VALU
+    per row): every stream token carries TWO rows.  Slots: 0..24 two rows of classes a, b (code 5a + b),
+    25..29 one row (the odd last row), 30 END, 31 REFILL (bgsa_common.h: pair_stream_window)."""
+    slot_of, n_slots = body.allocate_temps()
+
+    def reg_for(c: int):
+        def reg(name: str) -> str:
+            if name.startswith("S"):
+                return f"%[s{name[1:]}]"
+            if name.startswith("E"):
+                return f"%[e{c}_{name[1:]}]"
+            return f"%[t{slot_of[name]}]"
+        return reg
+
+    def disp() -> list[str]:
+        return [
+            f"s_and_b32 {S_C}, {S_WIN_LO}, 0x1f",
+            f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
+            f"s_mul_i32 {S_C}, {S_C}, (L_body1_%= - L_body0_%=)",
+            f"s_add_u32 {S_PC_LO}, {S_BASE_LO}, {S_C}",
+            f"s_addc_u32 {S_PC_HI}, {S_BASE_HI}, 0",
+            f"s_setpc_b64 {S_PC}",
+        ]
+
+    def pad(slot: int) -> str:
+        return f".fill ((L_body1_%= - L_body0_%=) - (L_end{slot}_%= - L_body{slot}_%=)) / 4, 4, 0xbf800000"
+
+    asm = [
+        f"s_mov_b64 {S_PTR}, %[qp]",
+        f"s_mov_b32 {S_LEFT}, %[nwin]",
+        f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+        f"s_getpc_b64 {S_PC}",
+        "L_anchor_%=:",
+        f"s_add_u32 {S_BASE_LO}, {S_PC_LO}, (L_body0_%= - L_anchor_%=)",
+        f"s_addc_u32 {S_BASE_HI}, {S_PC_HI}, 0",
+        "s_waitcnt lgkmcnt(0)",
+    ]
+    asm += disp()
+    for a in range(5):
+        for b2 in range(5):
+            asm.append(f"L_body{5 * a + b2}_%=:")
+            asm += body.emit_asm(reg_for(a), a)
+            asm += body.emit_asm(reg_for(b2), b2)
+            asm += disp()
+    for c in range(5):
+        asm.append(f"L_body{25 + c}_%=:")
+        asm += body.emit_asm(reg_for(c), c)
+        asm += disp()
+        asm.append(f"L_end{25 + c}_%=:")
+        asm.append(pad(25 + c))
+    asm.append("L_body30_%=:")  # END
+    asm.append("s_branch L_done_%=")
+    asm.append("L_end30_%=:")
+    asm.append(pad(30))
+    asm.append("L_body31_%=:")  # REFILL (same exit condition as gen_function)
+    asm += [
+        f"s_sub_u32 {S_LEFT}, {S_LEFT}, 1",
+        "s_cbranch_scc1 L_done_%=",
+        "s_waitcnt lgkmcnt(0)",
+        f"s_mov_b64 {S_WIN}, {S_NXT}",
+        f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 8",
+        f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+    ]
+    asm += disp()
+    asm.append("L_done_%=:")
+    asm.append("s_waitcnt lgkmcnt(0)")
+
+    text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
+    ins = [f'[e{c}_{j}] "v"(P[{c}][{j}])' for c in range(5) for j in range(n_eq)]
+    ins.append('[qp] "s"(stream)')
+    ins.append('[nwin] "s"(n_windows)')
+    clob = ", ".join(f'"{c}"' for c in CLOBBERS)
+    return f"""
+// two rows per token: {2 * body.valu_count()} VALU per token, {n_slots} temporaries
+template <>
+__device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
+                                                   const uint32_t (&P)[5][{n_eq}],
                                                    const unsigned long long stream,
                                                    const int n_windows)
 {{
@@ -498,6 +594,14 @@ def main() -> int:
              "                                               const unsigned long long stream, const int n_windows);\n"]
     for nw in MYERS_NW:  # G = 1 only: two groups per wave measured slower (fewer waves per SIMD)
         parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_body(nw, 1), 2 * nw, nw))
+    parts.append("\n// Short subjects: the row is so short that the scalar dispatch bounds the loop, so a stream token\n"
+                 "// carries two rows (bgsa_common.h: pair_stream_window).\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ void myers_pair_rows_asm(uint32_t (&state)[2 * NW],\n"
+                 "                                                    const uint32_t (&P)[5][NW],\n"
+                 "                                                    const unsigned long long stream, const int n_windows);\n")
+    for nw in MYERS_PAIR_NW:
+        parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}", R.myers_body(nw, 1), 2 * nw, nw))
     parts.append("\n// Long subjects (NW 9..32): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ void myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"

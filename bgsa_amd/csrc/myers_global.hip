@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 }
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
+constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"
 
 // Same task decomposition as above, but all rows of a query run inside one generated asm block:
@@ -200,7 +201,10 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
         }
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        if constexpr (G == 1 && NW <= kPairMaxWords)  // short rows: two per stream token (launch_asm packs it so)
+            myers_pair_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        else
+            myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
             int score = ref_len;  // D[m][n] = m + sum over the n subject columns of (VP - VN)
@@ -395,11 +399,14 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
         set_error_text("myers: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    constexpr bool kPairs = G == 1 && NW <= kPairMaxWords;
+    if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream)
+                        : launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream))
+        return rc;
     hipLaunchKernelGGL((myers_global_asm_kernel<NW, G>), grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, static_cast<int>(stream_stride(ref_len)));
+                       nq, q_tile, static_cast<int>(kPairs ? pair_stream_stride(ref_len) : stream_stride(ref_len)));
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

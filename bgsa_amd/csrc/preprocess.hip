@@ -171,6 +171,33 @@ int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int r
     return BGSA_HIP_OK;
 }
 
+__global__ __launch_bounds__(256) void pack_query_pairs_kernel(const char *__restrict__ content,
+                                                               unsigned long long *__restrict__ streams,
+                                                               int ref_len, int ref_start, int n_queries,
+                                                               int n_windows)
+{
+    const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int per = n_windows + 1;  // + the spare all-END window
+    if (tid >= static_cast<long long>(n_queries) * per) return;
+    const int q = static_cast<int>(tid / per), i = static_cast<int>(tid % per);
+    const char *row = content + static_cast<size_t>(ref_start + q) * (ref_len + 1);
+    streams[tid] = pair_stream_window(row, ref_len, i);
+}
+
+int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, int ref_end,
+                            void *d_streams, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    if (nq <= 0) return BGSA_HIP_OK;
+    const int n_windows = pair_stream_windows(ref_len);
+    const long long total = static_cast<long long>(nq) * (n_windows + 1);
+    hipLaunchKernelGGL(pack_query_pairs_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       stream, d_content, static_cast<unsigned long long *>(d_streams), ref_len, ref_start,
+                       nq, n_windows);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
 // One thread per query writes its banded stream (a few hundred bytes; the layout is sequential).
 __global__ __launch_bounds__(64) void pack_banded_kernel(const char *__restrict__ content,
                                                          unsigned char *__restrict__ streams, int len, int k,

@@ -209,8 +209,9 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
 
 /* Introspection (host only, no GPU): the packed code stream the kernels walk for one mapped query
  * row, 8-byte windows of 7 tokens + REFILL.  Myers / BitPAl: codes 0..4 = row of that character
- * class, 5 = END, 6 = REFILL; for BGSA_ALGO_MYERS, k < 0 selects the stream of the column-block
- * kernel (subjects > 1024 bp: a CARRY token, code 7, in front of every 32nd row).
+ * class, 5 = END, 6 = REFILL; for BGSA_ALGO_MYERS, k = -1 selects the stream of the column-block
+ * kernel (subjects > 1024 bp: a CARRY token, code 7, in front of every 32nd row) and k = -2 the
+ * two-rows-per-token stream of the <= 64 bp kernels (codes as for banded below, without EVENT).
  * BGSA_ALGO_BANDED (threshold k): 0..24 = two rows of classes a, b as 5*a + b, 25..29 = one row,
  * 30 = END, 31 = REFILL, 32 = EVENT + argument byte (1 reset the error count, 2 advance the match
  * words, 4 test the limit, 8 latch the reject mask).

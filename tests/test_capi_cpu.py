@@ -244,3 +244,19 @@ def test_myers_positive_weights_are_the_generators_m1(L):
     assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [0, 1, 1]
     assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
     assert [ctypes.c_int.in_dll(L, v).value for v in ("match_score", "mismatch_score", "gap_score")] == [0, -1, -1]
+
+
+@pytest.mark.parametrize("qlen", [1, 2, 13, 14, 15, 27, 28, 29, 64, 151, 1000])
+def test_two_rows_per_token_query_stream(L, qlen):
+    # the stream of the <= 64 bp Myers kernels (k = -2): tokens of two rows, an odd last row alone
+    rng = np.random.default_rng(qlen)
+    row = rng.integers(0, 5, qlen).astype(np.uint8)
+    n = L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, -2, None, 0)
+    buf = np.full(n, 0xEE, dtype=np.uint8)
+    assert L.bgsa_hip_query_stream(B.ALGO_MYERS, row.ctypes.data, qlen, -2, buf.ctypes.data, n) == n
+    assert [v for kind, v in _decode_banded_stream(buf) if kind == "row"] == row.tolist()
+    assert "event" not in {kind for kind, _ in _decode_banded_stream(buf)}
+    n_tokens = (qlen + 1) // 2
+    assert n == 8 * (n_tokens // 7 + 2) and (buf[-8:] == 30).all()
+    assert int((buf < 25).sum()) == qlen // 2 and int(((buf >= 25) & (buf < 30)).sum()) == qlen % 2
+    assert n <= L.bgsa_hip_workspace_bytes(B.ALGO_MYERS, qlen, 64, 1)     # sized for the longer one-row stream
