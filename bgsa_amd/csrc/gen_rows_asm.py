@@ -523,8 +523,9 @@ __device__ __forceinline__ void {fn_name}<{nw}>(uint32_t (&state)[{n_state}], {m
 
 def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int]]:
     """Kernel widths for one score set: plain kernels (state in registers for the whole subject) for
-    1..P words and column-block kernels for the four widths up to W, the widest that fit the VGPR
-    budget (at most 8: beyond that fewer waves per SIMD cost more than wider blocks gain)."""
+    1..P words, P the widest that fits the VGPR budget (at most 12; measured for 2/-3/-5: 9-11 words at
+    two waves per SIMD run at 27.8-28.5 TCUPS against 24.5 for the same subjects as column blocks), and
+    column-block kernels for the four widths up to W <= 8 (a block also carries 2 x chains carry words)."""
     def plain_regs(nw):
         return sc.planes * nw + 5 * nw + R.bitpal_body(nw, sc).allocate_temps()[1]
 
@@ -532,7 +533,7 @@ def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int]]:
         body, _ = R.bitpal_block_body(nw, sc)
         return sc.planes * nw + 5 * nw + body.allocate_temps()[1] + 2 * sc.chains + 2
 
-    plain = max(nw for nw in range(1, 9) if plain_regs(nw) <= BITPAL_VGPR_BUDGET)
+    plain = max(nw for nw in range(1, 13) if plain_regs(nw) <= BITPAL_VGPR_BUDGET)
     wide = max(nw for nw in range(1, 9) if block_regs(nw) <= BITPAL_BLOCK_VGPR_BUDGET)
     return list(range(1, plain + 1)), list(range(max(1, wide - 3), wide + 1))
 
