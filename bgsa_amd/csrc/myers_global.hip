@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 }
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
+constexpr int kPeqMaxWords = 8;   // default of myers_peq_max_words()
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"
 
@@ -510,6 +511,26 @@ int myers_max_plain_words()
     return limit;
 }
 
+// Widest subject (words) that keeps its five Peq planes in registers (10 VALU per word); wider ones use
+// the 3-bit code planes (11 per word, fewer registers).  BGSA_MYERS_PEQ_MAX_WORDS overrides (measurement).
+int myers_peq_max_words()
+{
+    static const int limit = [] {
+        const char *e = getenv("BGSA_MYERS_PEQ_MAX_WORDS");
+        const int v = e ? atoi(e) : kPeqMaxWords;
+        return (v >= 8 && v <= 24) ? v : kPeqMaxWords;
+    }();
+    return limit;
+}
+
+int pick_peq_nw(int word_num)
+{
+    if (word_num > myers_peq_max_words()) return -1;
+    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24})
+        if (nw >= word_num) return nw;
+    return -1;
+}
+
 const char *myers_kernel_name(int word_num)
 {
     static thread_local char name[64];
@@ -519,10 +540,12 @@ const char *myers_kernel_name(int word_num)
         snprintf(name, sizeof name, "myers_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
         return name;
     }
-    if (myers_impl() == 0 && word_num > 8 && pick_planes_nw(word_num) > 0)
+    if (myers_impl() == 0 && pick_peq_nw(word_num) > 0)
+        snprintf(name, sizeof name, "myers_global_asm_kernel<%d, 1>", pick_peq_nw(word_num));
+    else if (myers_impl() == 0 && pick_planes_nw(word_num) > 0)
         snprintf(name, sizeof name, "myers_global_planes_kernel<%d>", pick_planes_nw(word_num));
     else
-        snprintf(name, sizeof name, "%s<%d, 1>", (nw <= 8 && myers_impl() == 0) ? "myers_global_asm_kernel" : "myers_global_kernel", nw);
+        snprintf(name, sizeof name, "myers_global_kernel<%d, 1>", nw);
     return name;
 }
 
@@ -563,17 +586,19 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         }
     }
     if (myers_impl() == 0) {
-        switch (pick_nw(word_num)) {
+        switch (pick_peq_nw(word_num)) {
 #define BGSA_ASM_CASE(N)                                                                        \
     case N:                                                                                     \
         return launch_asm<N, 1>(d_content, d_peq, d_results, ref_len, read_len, read_count,     \
                                 ref_start, ref_end, word_num, d_workspace, stream);
             BGSA_ASM_CASE(1) BGSA_ASM_CASE(2) BGSA_ASM_CASE(3) BGSA_ASM_CASE(4) BGSA_ASM_CASE(5)
-            BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8)
+            BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8) BGSA_ASM_CASE(10) BGSA_ASM_CASE(12)
+            BGSA_ASM_CASE(14) BGSA_ASM_CASE(16) BGSA_ASM_CASE(18) BGSA_ASM_CASE(20) BGSA_ASM_CASE(22)
+            BGSA_ASM_CASE(24)
 #undef BGSA_ASM_CASE
         default: break;
         }
-        switch (word_num > 8 ? pick_planes_nw(word_num) : -1) {
+        switch (pick_planes_nw(word_num)) {
 #define BGSA_PLANES_CASE(N)                                                                     \
     case N:                                                                                     \
         return launch_planes<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,     \
