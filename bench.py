@@ -69,10 +69,11 @@ def issued_valu_per_row(algo: int, wn: int, scores=None):
         import rows_ir as R
     except Exception:
         return None
-    if algo == B.ALGO_MYERS and wn <= 8:
-        return R.myers_body(wn).valu_count()
-    if algo == B.ALGO_MYERS and wn <= 32:
-        nw = next(n for n in range(10, 33, 2) if n >= wn)
+    if algo == B.ALGO_MYERS and wn <= 24:      # Peq planes resident (myers_global_asm_kernel)
+        nw = wn if wn <= 8 else next(n for n in range(10, 25, 2) if n >= wn)
+        return R.myers_body(nw).valu_count()
+    if algo == B.ALGO_MYERS and wn <= 32:      # 3-bit code planes (myers_global_planes_kernel)
+        nw = next(n for n in range(26, 33, 2) if n >= wn)
         return R.myers_planes_body(nw).valu_count()
     if algo == B.ALGO_BITPAL and wn <= 8:
         return R.bitpal_body(wn, R.BitpalScores(*scores) if scores else R.BITPAL_DEFAULT).valu_count()

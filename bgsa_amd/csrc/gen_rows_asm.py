@@ -603,7 +603,7 @@ def main() -> int:
                  "                                                    const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PAIR_NW:
         parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}", R.myers_body(nw, 1), 2 * nw, nw))
-    parts.append("\n// Long subjects (NW 9..32): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
+    parts.append("\n// Long subjects (NW 26..32; the widths below 26 serve the column-block kernel and A/B runs): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ void myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"
                  "                                                      const uint32_t (&B)[3 * NW],\n"

@@ -18,8 +18,8 @@
 //     D[m][n] = m + popcount(VP & mask) - popcount(VN & mask), two v_bcnt per word.
 //
 // Three kernels, chosen by launch_myers():
-//   myers_global_asm_kernel<NW,1>   1..256 bp    generated asm row loop, 10 VALU per (row, word)
-//   myers_global_planes_kernel<NW>  257..1024 bp generated asm row loop on 3-bit character-code
+//   myers_global_asm_kernel<NW,1>   1..768 bp    generated asm row loop, Peq planes resident, 10 VALU per (row, word)
+//   myers_global_planes_kernel<NW>  769..1024 bp generated asm row loop on 3-bit character-code
 //                                                planes, 11 VALU per (row, word)
 //   myers_global_kernel<NW,1>       compiler-scheduled C++ of the same recurrence: the A/B
 //                                   reference for the asm (BGSA_MYERS_IMPL=c), 124 vs 216 TCUPS
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 }
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
-constexpr int kPeqMaxWords = 8;   // default of myers_peq_max_words()
+constexpr int kPeqMaxWords = 24;  // default of myers_peq_max_words(): measured faster than the code planes up to here
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"
 
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     }
 }
 
-// Long subjects (257..1024 bp): the wave turns its five Peq planes into the subject's 3-bit
+// Long subjects (769..1024 bp; 257..1024 before the Peq-resident kernels were widened): the wave turns its five Peq planes into the subject's 3-bit
 // character-code planes once per task (B0 = C|T, B1 = G|T, B2 = N) and the row body rebuilds the
 // match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 11 VALU per
 // word, 7*NW+1 registers, two waves per SIMD at NW = 32.

@@ -344,7 +344,7 @@ def myers_body(nw: int, groups: int = 1) -> Body:
 
 
 def myers_planes_body(nw: int) -> Body:
-    """Myers for long subjects (257..1024 bp): the five Peq planes of a subject (5*nw registers)
+    """Myers for long subjects (769..1024 bp): the five Peq planes of a subject (5*nw registers)
     are replaced by its 3-bit character code planes B[w*3+i] (3*nw registers) and the match mask
     of the row's class is rebuilt per word with one v_bitop3 (MATCH3) — 11 instructions per word,
     7*nw+1 registers, which keeps 32 words (1024 bp) at two waves per SIMD.  State as myers_body.
