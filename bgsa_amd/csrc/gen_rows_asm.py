@@ -32,6 +32,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 import rows_ir as R  # noqa: E402
 
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24]  # Peq masks resident: 10 VALU per word
+MYERS_PEQ_BLOCK_NW = [12, 14, 16, 18, 20]  # column blocks with resident Peq planes (20 words: 238 VGPRs; 22 would need 256)
 MYERS_PAIR_NW = [1, 2]  # two rows per stream token: the 10-20 VALU row cannot hide the scalar dispatch
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word
 MYERS_BLOCK_NW = [12, 14, 16, 18, 20, 22, 24, 26, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
@@ -619,6 +620,14 @@ def main() -> int:
                  "                                                     const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_BLOCK_NW:
         parts.append(gen_blocked_function("myers_block_rows_asm", nw, R.myers_block_body(nw), 2 * nw, 3, 3 * nw, 0))
+    parts.append("\n// The same with the five Peq planes of the block resident instead of the code planes: 10 VALU per word,\n"
+                 "// narrower blocks (rows_ir.py: myers_peq_block_body).\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ void myers_peq_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&P)[5][NW],\n"
+                 "                                                         uint32_t &voff, const unsigned long long carry_base,\n"
+                 "                                                         const unsigned long long stream, const int n_windows);\n")
+    for nw in MYERS_PEQ_BLOCK_NW:
+        parts.append(gen_blocked_function("myers_peq_block_rows_asm", nw, R.myers_peq_block_body(nw), 2 * nw, 3, 0, nw))
     (here / "myers_rows_gen.inc").write_text("".join(parts))
     # ---- BitPAl, default scores (other score sets: gen_bitpal_sets.py) ------------------------
     (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
 // through its carry buffer ([32-row chunk][add, HP, HN][lane] words in the workspace, first row in
 // bit 31 — rows_ir.py: myers_block_body).  A fixed number of workgroups loops over the tasks so
 // that the buffer count does not grow with the problem.
-template <int NW>
+template <int NW, bool PEQ = false>
 __global__ __launch_bounds__(256) void myers_blocked_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
@@ -310,16 +310,22 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                 reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
             int score = ref_len;
             for (int blk = 0; blk < n_blocks; blk++) {
-                uint32_t Bp[3 * NW];
+                uint32_t Bp[PEQ ? 1 : 3 * NW];       // 3-bit character-code planes of the block, or
+                uint32_t Pq[kChars][PEQ ? NW : 1];   // its five Peq planes (PEQ: 10 VALU per word, narrower blocks)
 #pragma unroll
                 for (int w = 0; w < NW; w++) {
                     const int gw = blk * NW + w;
                     uint32_t p[kChars];
 #pragma unroll
                     for (int c = 0; c < kChars; c++) p[c] = (gw < word_num) ? g[(c * word_num + gw) * kLanes] : 0u;
-                    Bp[3 * w + 0] = p[1] | p[3];
-                    Bp[3 * w + 1] = p[2] | p[3];
-                    Bp[3 * w + 2] = p[4];
+                    if constexpr (PEQ) {
+#pragma unroll
+                        for (int c = 0; c < kChars; c++) Pq[c][w] = p[c];
+                    } else {
+                        Bp[3 * w + 0] = p[1] | p[3];
+                        Bp[3 * w + 1] = p[2] | p[3];
+                        Bp[3 * w + 2] = p[4];
+                    }
                 }
                 uint32_t st[2 * NW + 6];
 #pragma unroll
@@ -333,8 +339,12 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                     st[2 * NW + 3 + i] = 0u;
                 }
                 uint32_t voff = static_cast<uint32_t>(lane * 4);
-                myers_block_rows_asm<NW>(st, Bp, voff, carry_base, uniform_u64(s),
-                                         __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                if constexpr (PEQ)
+                    myers_peq_block_rows_asm<NW>(st, Pq, voff, carry_base, uniform_u64(s),
+                                                 __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                else
+                    myers_block_rows_asm<NW>(st, Bp, voff, carry_base, uniform_u64(s),
+                                             __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
                 // carry-out words of the last (possibly partial) chunk, first row left-aligned
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
@@ -436,7 +446,7 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
     return BGSA_HIP_OK;
 }
 
-template <int NW>
+template <int NW, bool PEQ = false>
 int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
                    int64_t read_count, int ref_start, int ref_end, int word_num, int n_blocks, void *d_workspace,
                    hipStream_t stream)
@@ -446,7 +456,7 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     const size_t stream_bytes = (static_cast<size_t>(stride) * nq + 255) & ~static_cast<size_t>(255);
     if (int rc = launch_pack_blocked(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
     uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
-    hipLaunchKernelGGL((myers_blocked_kernel<NW>), dim3(blocked_workgroups()), dim3(256), 0, stream,
+    hipLaunchKernelGGL((myers_blocked_kernel<NW, PEQ>), dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
                        stride, n_blocks);
@@ -463,6 +473,30 @@ int pick_block_nw(int word_num, int *n_blocks)
     const int blocks = (word_num + kWidest - 1) / kWidest;
     const int need = (word_num + blocks - 1) / blocks;
     for (int nw : {12, 14, 16, 18, 20, 22, 24, 26, 28})
+        if (nw >= need) {
+            *n_blocks = (word_num + nw - 1) / nw;
+            return nw;
+        }
+    *n_blocks = blocks;
+    return kWidest;
+}
+
+// Column blocks with resident Peq planes: 12..20 words (BGSA_MYERS_BLOCK_FORM=planes selects the
+// code-plane blocks of up to 28 words instead, the A/B reference).
+bool peq_blocks()
+{
+    static const bool on = [] {
+        const char *e = getenv("BGSA_MYERS_BLOCK_FORM");
+        return !(e && e[0] == 'p');
+    }();
+    return on;
+}
+int pick_peq_block_nw(int word_num, int *n_blocks)
+{
+    constexpr int kWidest = 20;  // 238 VGPRs: two waves per SIMD (22 words would need 256)
+    const int blocks = (word_num + kWidest - 1) / kWidest;
+    const int need = (word_num + blocks - 1) / blocks;
+    for (int nw : {12, 14, 16, 18, 20})
         if (nw >= need) {
             *n_blocks = (word_num + nw - 1) / nw;
             return nw;
@@ -537,7 +571,10 @@ const char *myers_kernel_name(int word_num)
     const int nw = pick_nw(word_num);
     if (word_num > myers_max_plain_words()) {
         int n_blocks = 0;
-        snprintf(name, sizeof name, "myers_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
+        if (peq_blocks())
+            snprintf(name, sizeof name, "myers_blocked_kernel<%d, true>", pick_peq_block_nw(word_num, &n_blocks));
+        else
+            snprintf(name, sizeof name, "myers_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
         return name;
     }
     if (myers_impl() == 0 && pick_peq_nw(word_num) > 0)
@@ -572,6 +609,18 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
     if (word_num > myers_max_plain_words() && myers_impl() == 1)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_MYERS, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);
+    if (word_num > myers_max_plain_words() && peq_blocks()) {
+        int n_blocks = 0;
+        switch (pick_peq_block_nw(word_num, &n_blocks)) {
+#define BGSA_BLOCK_CASE(N)                                                                       \
+    case N:                                                                                      \
+        return launch_blocked<N, true>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
+                                       ref_end, word_num, n_blocks, d_workspace, stream);
+            BGSA_BLOCK_CASE(12) BGSA_BLOCK_CASE(14) BGSA_BLOCK_CASE(16) BGSA_BLOCK_CASE(18) BGSA_BLOCK_CASE(20)
+#undef BGSA_BLOCK_CASE
+        default: break;
+        }
+    }
     if (word_num > myers_max_plain_words()) {
         int n_blocks = 0;
         switch (pick_block_nw(word_num, &n_blocks)) {

@@ -409,9 +409,19 @@ def myers_block_body(nw: int) -> Body:
     return schedule(b, 16)   # fills the slots around the carry-word instructions
 
 
-def myers_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int) -> np.ndarray:
+def myers_peq_block_body(nw: int) -> Body:
+    """Column-block form of myers_body (Peq planes resident, 10 VALU per word + 6 for the carry words),
+    derived mechanically like the BitPAl block bodies.  Chains: addition (carry-in 0), HP shift (carry-in
+    1 in the first block: the row edge), HN shift (0)."""
+    body, init = make_blocked(myers_body(nw, 1), 2 * nw)
+    assert init == [0, 1, 0]
+    return schedule(body, 16)
+
+
+def myers_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int, peq_resident: bool = False) -> np.ndarray:
     """A subject processed as column blocks of nw_block words with the block body, carries
-    exchanged through per-32-row words exactly as myers_blocked_kernel does.  Returns int16."""
+    exchanged through per-32-row words exactly as myers_blocked_kernel does.  Returns int16.
+    peq_resident: the block body built on myers_body (match masks in registers) instead of the code planes."""
     n, slen = subjects.shape
     qlen = len(query)
     nw_total = (slen + 31) // 32
@@ -423,7 +433,7 @@ def myers_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: in
     FULL = np.uint32(0xFFFFFFFF)
     # carry words per 32-row chunk: addition carry-in 0, HP carry-in 1 (row edge), HN carry-in 0
     carry = [[np.zeros(n, np.uint32), np.full(n, FULL, np.uint32), np.zeros(n, np.uint32)] for _ in range(n_chunks)]
-    body = myers_block_body(nw_block)
+    body = myers_peq_block_body(nw_block) if peq_resident else myers_block_body(nw_block)
     score = np.full(n, qlen, dtype=np.int64)
     for blk in range(n_blocks):
         st = []
@@ -437,7 +447,11 @@ def myers_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: in
                 carry[j - 1] = [st[2 * nw_block + 3 + i].copy() for i in range(3)]
                 for i in range(3):
                     st[2 * nw_block + i] = carry[j][i].copy()
-            body.simulate(st, [], cls=code.get(int(ch), 0), planes=planes)
+            c = code.get(int(ch), 0)
+            if peq_resident:
+                body.simulate(st, [peq[c, blk * nw_block + w] for w in range(nw_block)])
+            else:
+                body.simulate(st, [], cls=c, planes=planes)
         tail = qlen % 32
         last = [st[2 * nw_block + 3 + i] for i in range(3)]
         if tail:

@@ -274,3 +274,15 @@ def test_bitpal_semiglobal_matches_dp(oracle, scores, qlen, slen):
         assert np.array_equal(R.bitpal_blocked_simulate(s, q[i], 2, sc, semi=True), want[i])
     if slen >= qlen:
         assert want[:, :20].max(axis=0).min() > want[:, 20:].max()   # the planted copies beat every random subject
+
+
+@pytest.mark.parametrize("qlen,slen,nwb", [(150, 150, 2), (70, 200, 3), (33, 97, 1), (64, 64, 1), (100, 300, 4), (31, 150, 2)])
+def test_myers_peq_resident_column_blocks(oracle, qlen, slen, nwb):
+    # the block body derived mechanically from myers_body (Peq planes resident) with carry words
+    q = oracle.gen_reads(40 + qlen, 2, qlen)
+    s = oracle.gen_reads(50 + slen, 64, slen)
+    m = min(qlen, slen)
+    s[:8, :m] = oracle.mutate(q[np.arange(8) % 2][:, :m], np.arange(8), 60)
+    want = oracle.myers64(q, s)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.myers_blocked_simulate(s, q[i], nwb, peq_resident=True), want[i])
