@@ -28,6 +28,7 @@
 //
 // Integer/bitwise only; no LDS, no MFMA.  The kernels are VALU-issue bound.
 #include <stdlib.h>
+#include <string.h>
 
 #include "bgsa_common.h"
 
@@ -487,7 +488,7 @@ bool peq_blocks()
 {
     static const bool on = [] {
         const char *e = getenv("BGSA_MYERS_BLOCK_FORM");
-        return !(e && e[0] == 'p');
+        return !(e && strcmp(e, "planes") == 0);
     }();
     return on;
 }
