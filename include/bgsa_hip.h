@@ -192,7 +192,7 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream);
 /* Scratch the hot path needs for n_queries queries of ref_len characters against subjects of
  * read_len characters: the queries re-packed into 8-byte-aligned code streams the kernels fetch
  * through the scalar cache, plus, for subjects too long for the register-resident kernels (Myers
- * > 1024 bp, BitPAl beyond the plain widths of the selected score set, > 256 bp for 2/-3/-5), the
+ * > 1024 bp, BitPAl beyond the plain widths of the selected score set, > 352 bp for 2/-3/-5), the
  * per-wave carry words of the column-block kernels.  Depends on the selected score set. */
 size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries);
 
