@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
 #pragma unroll
                     for (int w = 0; w < NW; w++) {
                         const int gw = blk * NW + w;
-                        P[c][w] = (gw < word_num) ? g[(c * word_num + gw) * kLanes] : 0u;
+                        const int gwc = gw < word_num ? gw : word_num - 1;   // branch-free: see myers_blocked_kernel
+                        P[c][w] = g[(c * word_num + gwc) * kLanes] & (gw < word_num ? ~0u : 0u);
                     }
                 uint32_t st[NS + 2 * NC];
 #pragma unroll

@@ -317,8 +317,12 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                 for (int w = 0; w < NW; w++) {
                     const int gw = blk * NW + w;
                     uint32_t p[kChars];
+                    // unconditional loads (index clamped, result masked): a guarded load becomes a branch per
+                    // word, and this runs per query and block, not once per task as in the plain kernels
+                    const int gwc = gw < word_num ? gw : word_num - 1;
+                    const uint32_t keep = gw < word_num ? ~0u : 0u;
 #pragma unroll
-                    for (int c = 0; c < kChars; c++) p[c] = (gw < word_num) ? g[(c * word_num + gw) * kLanes] : 0u;
+                    for (int c = 0; c < kChars; c++) p[c] = g[(c * word_num + gwc) * kLanes] & keep;
                     if constexpr (PEQ) {
 #pragma unroll
                         for (int c = 0; c < kChars; c++) Pq[c][w] = p[c];
