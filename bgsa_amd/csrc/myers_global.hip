@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
     const int q_tiles = (n_queries + q_tile - 1) / q_tile;
     const long long n_tasks = static_cast<long long>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock) * q_tiles;
     const int tail_rows = ref_len & 31;
+    dephase_persistent_workgroup();
 
     for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const int group = __builtin_amdgcn_readfirstlane(static_cast<int>(task / q_tiles) * kWavesPerBlock + wave);
