@@ -107,9 +107,13 @@ int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, i
 constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill = kPairRefill, kBandedEvent = 32;
 // Upper bound of banded_stream_layout(len, k) over every k (sizes the workspace, which does not know k):
 // all rows as one-row tokens, every event two bytes plus one byte lost to an early window close.
+// Rows between two tests of the error limit (a wave stops as soon as all 64 lanes are past it).  The
+// reference tests every 16 rows (banded/BGSA_CPU/config.h: batch_size); the errors never decrease, so
+// testing more often rejects exactly the same pairs, only sooner.
+constexpr int kBandedCheckRows = 8;
 inline size_t banded_stream_bound(int len)
 {
-    const size_t events = static_cast<size_t>(len) / 16 + static_cast<size_t>(len) / 32 + 4;
+    const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 + 4;
     return (static_cast<size_t>(len) + 3 * events + 1 + 6) / 7 * 8 + 16;
 }
 __host__ __device__ inline int banded_stream_layout(int len, int k, const char *row, unsigned char *dst)
@@ -142,7 +146,7 @@ __host__ __device__ inline int banded_stream_layout(int len, int k, const char *
     // events due before row r starts / after `done` rows are complete
     auto before = [&](int r) { return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0); };
     auto after = [&](int done) {
-        return (done > k && done <= last && ((done & 15) == 0 || done == last)) ? (4 | (done == last ? 8 : 0)) : 0;
+        return (done > k && done <= last && ((done & (kBandedCheckRows - 1)) == 0 || done == last)) ? (4 | (done == last ? 8 : 0)) : 0;
     };
     for (int r = 0; r < len;) {
         pending |= before(r);

@@ -556,6 +556,9 @@ def banded_last_check(length: int, k: int) -> int:
     return length if length <= 64 else max(64, length - h)
 
 
+BANDED_CHECK_ROWS = 8   # bgsa_common.h: kBandedCheckRows
+
+
 def banded_tokens(length: int, k: int, word_bits: int = 32):
     """The per-query token sequence of the banded stream, query characters as ('row', r):
     ('event', bits) with bits 1 = reset the error count (row k), 2 = advance the match-string
@@ -573,7 +576,7 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
             pending = 0
         out.append(("row", r))
         done = r + 1
-        if done > k and done <= last and (done % 16 == 0 or done == last):
+        if done > k and done <= last and (done % BANDED_CHECK_ROWS == 0 or done == last):
             pending |= 4 | (8 if done == last else 0)
     if pending:
         out.append(("event", pending))
