@@ -11,7 +11,7 @@
 // (rows_ir.py: bitpal_body), every inter-word carry a VCC add-with-carry chain on full 32-bit words.
 //
 // Final score (align_core.c:433-471 generalised): gap*(qlen + slen) + sum over subject columns of
-// (dH - gap), i.e. one masked popcount per plane and word, weighted by kBitpalWeights.
+// u = dH - gap, i.e. one masked popcount per plane and word, weighted 2^plane (kBitpalWeights).
 
 template <int NW>
 __device__ __forceinline__ int bitpal_column_sum(const uint32_t *st, int first_word, int read_len)
@@ -47,11 +47,11 @@ __device__ __forceinline__ void bitpal_last_row_max(const uint32_t *st, int firs
     }
 }
 
-// Row 0 of the DP: dH = gap everywhere (global: stored -u = 0) or dH = 0 (semi-global: u = -gap,
-// writeBitInitStr, BitPAlGenerator.java:2201-2218).
+// Row 0 of the DP: dH = gap everywhere (global: u = 0) or dH = 0 (semi-global: u = -gap,
+// writeBitInitStr, BitPAlGenerator.java:2201-2218).  The planes hold u itself, unsigned.
 __device__ __forceinline__ uint32_t bitpal_init_plane(int plane, int semi)
 {
-    constexpr uint32_t stored = static_cast<uint32_t>(kBitpalGap) & ((1u << kBitpalPlanes) - 1u);
+    constexpr uint32_t stored = static_cast<uint32_t>(-kBitpalGap);
     return (semi && ((stored >> plane) & 1u)) ? ~0u : 0u;
 }
 

@@ -546,8 +546,8 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
     per_word = R.bitpal_body(1, sc).valu_count()
     case = lambda ws: " ".join(f"X({w})" for w in ws)
     parts = ["// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n",
-             f"// BitPAl packed, match {sc.match} / mismatch {sc.mismatch} / gap {sc.gap}: {B} planes per word (two's complement of\n"
-             f"// -(dH - gap), values 0..{sc.C}), {sc.K} value classes above the mismatch class {sc.D}, {NC} carry chains,\n"
+             f"// BitPAl packed, match {sc.match} / mismatch {sc.mismatch} / gap {sc.gap}: {B} planes per word (u = dH - gap, unsigned,\n"
+             f"// values 0..{sc.C}), {sc.K} value classes above the mismatch class {sc.D}, {NC} carry chains,\n"
              f"// {per_word} VALU per (row, word).\n"
              f"constexpr int kBitpalMatch = {sc.match}, kBitpalMismatch = {sc.mismatch}, kBitpalGap = {sc.gap};\n"
              f"constexpr int kBitpalPlanes = {B};\n"
@@ -559,7 +559,7 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
              f"#define BGSA_BITPAL_PLAIN_WIDTHS(X) {case(plain)}\n"
              f"#define BGSA_BITPAL_BLOCK_WIDTHS(X) {case(blocks)}\n"
              "// All rows of one query against one group.  state[w*kBitpalPlanes+i] = plane i of word w\n"
-             "// (plane kBitpalPlanes-1 = sign); P[c][w] = match mask of character class c.\n"
+             "// (weight 2^i); P[c][w] = match mask of character class c.\n"
              "template <int NW>\n"
              "__device__ __forceinline__ void bitpal_rows_asm(uint32_t (&state)[kBitpalPlanes * NW],\n"
              "                                                const uint32_t (&P)[5][NW],\n"

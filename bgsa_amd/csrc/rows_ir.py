@@ -732,7 +732,7 @@ def _banded_simulate64(subjects: np.ndarray, query: np.ndarray, k: int) -> np.nd
 # reference's generator emits per score set (generator/.../BitPAlGenerator.java:151-534 packed form,
 # ScoreMsg.java:23-31 for the value ranges), restated on normalised differences.
 #
-#   u_j = dH(row above, column j) - G   in [0, C],  C = M - 2G      (stored as B-bit two's complement of -u)
+#   u_j = dH(row above, column j) - G   in [0, C],  C = M - 2G      (stored unsigned on bits(C) planes)
 #   v_j = dV(column j)            - G   in [0, C]
 #   v_j = max(0, w_j - u_j),  w_j = C at a match, else max(D, v_{j-1}),  D = I - 2G
 #   new u_j = max(0, max(W_j, u_j) - v_{j-1}),  W_j = C at a match, D otherwise
@@ -761,7 +761,7 @@ class BitpalScores:
     @property
     def nb(self) -> int: return self.C.bit_length()               # magnitude planes
     @property
-    def planes(self) -> int: return self.nb + 1                   # + sign plane
+    def planes(self) -> int: return self.nb                       # unsigned u: no sign plane
     @property
     def chains(self) -> int: return 1 + 2 * (self.K - 1) + self.nb
     @property
@@ -770,8 +770,8 @@ class BitpalScores:
         return f"{f(self.match)}_{f(self.mismatch)}_{f(self.gap)}"
 
     def weights(self) -> tuple:
-        """Per-plane weight of a set bit in the final score: u = 2^(B-1) p_(B-1) - sum 2^i p_i."""
-        return tuple(-(1 << i) for i in range(self.nb)) + (1 << self.nb,)
+        """Per-plane weight of a set bit in the final score: u = sum 2^i p_i."""
+        return tuple(1 << i for i in range(self.nb))
 
 
 BITPAL_DEFAULT = BitpalScores(2, -3, -5)
@@ -843,16 +843,17 @@ class _Bool:
 
 
 def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
-    """Row body for `nw` words.  State S[w*B + i] = plane i of word w (B = sc.planes, plane B-1 the
-    sign); E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed
-    shift and its run, then the nb plane shifts — sc.chains in all."""
-    B, nb, C, D, K = sc.planes, sc.nb, sc.C, sc.D, sc.K
+    """Row body for `nw` words.  State S[w*B + i] = plane i (weight 2^i) of the UNSIGNED value u of word
+    w's 32 columns, B = sc.planes = bits(C) (the reference keeps the two's complement of -u in one more
+    plane, align_core.c:191-214; the unsigned form saves that plane and four instructions per word).
+    E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed shift and its
+    run, then the B plane shifts — sc.chains in all."""
+    B, C, D, K = sc.planes, sc.C, sc.D, sc.K
     b = Body()
-    H = lambda w, i: f"S{w * B + i}"
+    U = lambda w, i: f"S{w * B + i}"
     E = lambda w: f"E{w}"
     t = lambda name, w: f"{name}_{w}"
     W = range(nw)
-    full = (1 << B) - 1
     z = {}      # (value of u, word) -> one-hot mask name
     anym = {}   # word -> mismatch columns whose u <= D
     dv = {}     # (class offset c, word) -> columns whose incoming v is C - c (c = 0: or a match)
@@ -860,34 +861,53 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     # ---- decode the u classes the seeds need, the "u <= D" mask, and the top-class run ----------
     for w in W:
         bx = _Bool(b, f"d{w}")
-        msb_first = [H(w, i) for i in range(B - 1, -1, -1)]
-        low = bx.or_all([H(w, i) for i in range(B - 2)], "lo") if B > 3 else H(w, 0)
-        z0 = bx.op3(lambda a, b_, c: ~(a | b_ | c), low, H(w, B - 2), H(w, B - 1), "z0")   # u == 0
+        planes = [U(w, i) for i in range(B)]
+        msb_first = planes[::-1]
+        if B == 1:
+            z0 = bx.op3(lambda a, _a, __a: ~a, planes[0], planes[0], planes[0], "z0")
+        elif B == 2:
+            z0 = bx.op3(lambda a, b_, _b: ~(a | b_), planes[0], planes[1], planes[1], "z0")
+        else:
+            low = bx.or_all(planes[:B - 2], "lo") if B > 3 else planes[0]
+            z0 = bx.op3(lambda a, b_, c: ~(a | b_ | c), low, planes[B - 2], planes[B - 1], "z0")   # u == 0
         for x in range(1, K):
-            pat = (full + 1 - x) & full
-            z[x, w] = bx.and_pattern(msb_first, [(pat >> i) & 1 for i in range(B - 1, -1, -1)])
-        # u <= D  <=>  u == 0 or stored value >= 2^B - D: constant comparator from the LSB up
-        # (r = "the bits seen so far are >= the constant's"; a one bit ANDs the plane in, a zero ORs it)
-        if D > 0:
-            t0 = (full + 1 - D) & full
-            step = lambda rv, p, bit: (p & rv) if bit else (p | rv)
-            i = 0
-            while not (t0 >> i) & 1:      # trailing zero bits of the constant: always satisfied
-                i += 1
-            r = H(w, i)
+            z[x, w] = bx.and_pattern(msb_first, [(x >> i) & 1 for i in range(B - 1, -1, -1)]) if B > 1 else planes[0]
+        # u <= D: constant comparator from the LSB up (r = "the bits seen so far are <= the constant's";
+        # a one bit of D ORs the complemented plane in, a zero bit ANDs it)
+        step = lambda rv, p, bit: (~p | rv) if bit else (~p & rv)
+        i = 0
+        while i < B and (D >> i) & 1:      # trailing one bits of the constant: always satisfied
             i += 1
+        if i >= B:
+            anym[w] = bx.op3(lambda e, _e, __e: ~e, E(w), E(w), E(w), "any")          # every u is <= D
+        else:
+            r = None
+            first = i
+            i += 1
+            # the first zero bit: r = ~plane
+            pending = [("not", planes[first])]
+            cur = None
             while i < B:
-                b0 = (t0 >> i) & 1
+                b0 = (D >> i) & 1
                 if i + 1 < B:
-                    b1 = (t0 >> (i + 1)) & 1
-                    r = bx.op3(lambda x1, x0, rv, b0=b0, b1=b1: step(step(rv, x0, b0), x1, b1), H(w, i + 1), H(w, i), r, "ge")
+                    b1 = (D >> (i + 1)) & 1
+                    if cur is None:
+                        cur = bx.op3(lambda x1, x0, p, b0=b0, b1=b1: step(step(~p, x0, b0), x1, b1),
+                                     planes[i + 1], planes[i], planes[first], "le")
+                    else:
+                        cur = bx.op3(lambda x1, x0, rv, b0=b0, b1=b1: step(step(rv, x0, b0), x1, b1),
+                                     planes[i + 1], planes[i], cur, "le")
                     i += 2
                 else:
-                    r = bx.op2("AND" if b0 else "OR", H(w, i), r, "ge")
+                    if cur is None:
+                        cur = bx.op3(lambda x0, p, _p, b0=b0: step(~p, x0, b0), planes[i], planes[first], planes[first], "le")
+                    else:
+                        cur = bx.op3(lambda x0, rv, _r, b0=b0: step(rv, x0, b0), planes[i], cur, cur, "le")
                     i += 1
-            anym[w] = bx.op3(lambda ge, z_, e: (ge | z_) & ~e, r, z0, E(w), "any")
-        else:
-            anym[w] = bx.op3(lambda z_, e, _e: z_ & ~e, z0, E(w), E(w), "any")
+            if cur is None:   # the comparison is just "~plane[first]"
+                anym[w] = bx.op3(lambda p, e, _e: ~p & ~e, planes[first], E(w), E(w), "any")
+            else:
+                anym[w] = bx.op3(lambda le, e, _e: le & ~e, cur, E(w), E(w), "any")
         b.AND(t("seed", w), z0, E(w))
         b.XOR(t("run", w), z0, t("seed", w))                       # u == 0 at a mismatch
         (b.ADD_CO if w == 0 else b.ADDC)(t("sum", w), t("seed", w), z0)
@@ -908,22 +928,42 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
                 b.BITOP3(t(f"seed{c}", w), z[c - x, w], dv[x, w], t(f"seed{c}", w), lambda a, b_, acc: (a & b_) | acc)
         shifted_run(f"seed{c}", c)
 
-    # ---- w planes, v = max(0, w - u) -----------------------------------------------------------------
+    # ---- w planes, v = max(0, w - u) = (w + ~u + 1) where that does not borrow, else 0 ------------------
     lit = {"reg": lambda x: x, "not": lambda x: ~x, "zero": lambda x: 0, "one": lambda x: 0xFF}
+
+    def subtract(w, minuend, sub_name, out_name):
+        """out = max(0, minuend - sub) over B planes; minuend[i] = (kind, register name or None)."""
+        carry = None
+        for i in range(B):
+            kind, name = minuend[i]
+            f = lit[kind]
+            src = name if name is not None else sub_name(i)
+            if carry is None:      # bit 0: the +1 of the two's complement is the carry-in
+                if kind == "reg":
+                    b.XOR(t(f"{out_name}{i}", w), src, sub_name(i))
+                else:
+                    b.BITOP3(t(f"{out_name}{i}", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) ^ s)
+                carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) | ~s)
+            else:
+                b.BITOP3(t(f"{out_name}{i}", w), src, sub_name(i), carry, lambda m, s, cy, f=f: f(m) ^ ~s ^ cy)
+                carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), carry,
+                                 lambda m, s, cy, f=f: (f(m) & ~s) | (f(m) & cy) | (~s & cy))
+        return carry     # 1 = no borrow: the difference is >= 0
+
     for w in W:
         bx = _Bool(b, f"w{w}")
         cls_mask = {C - c: dv[c, w] for c in range(K)}
         # plane i of w over the columns: classes above D contribute their masks, class D is "the rest".
         # Either spell every plane from the class masks alone, or spend the ops for rest = ~OR(all masks)
         # once and use it as one more mask — whichever costs fewer instructions overall.
-        or_cost = lambda n: 0 if n <= 1 else (n - 1 + 1) // 2
-        have = [[v for v in cls_mask if (v >> i) & 1] for i in range(nb)]
-        lack = [[v for v in cls_mask if not (v >> i) & 1] for i in range(nb)]
-        d_bit = [(D >> i) & 1 for i in range(nb)]
+        or_cost = lambda n: 0 if n <= 1 else n // 2
+        have = [[v for v in cls_mask if (v >> i) & 1] for i in range(B)]
+        lack = [[v for v in cls_mask if not (v >> i) & 1] for i in range(B)]
+        d_bit = [(D >> i) & 1 for i in range(B)]
 
         def plan(with_rest):
             total, choice = (or_cost(K) if with_rest else 0), []
-            for i in range(nb):
+            for i in range(B):
                 opts = []
                 if with_rest:   # rest joins the side class D is on
                     opts.append((or_cost(len(have[i]) + d_bit[i]), "reg", have[i], bool(d_bit[i])))
@@ -949,72 +989,36 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
             else:
                 head = bx.or_all(allm[:-2], "hi") if len(allm) > 3 else allm[0]
                 rest = bx.op3(lambda a, b_, c: ~(a | b_ | c), head, allm[-2], allm[-1], "rest")
-        planes = []   # (kind, name): plane i of w is name / ~name / 0 / 1
+        wplanes = []   # (kind, name): plane i of w is name / ~name / 0 / 1
         for _cost, kind, vals, plus_rest in (choice_r if use_rest else choice_n):
             masks = [cls_mask[v] for v in vals] + ([rest] if plus_rest else [])
             if not masks:
-                planes.append(("zero" if kind == "reg" else "one", None))
+                wplanes.append(("zero" if kind == "reg" else "one", None))
             else:
-                planes.append((kind, bx.or_all(masks, "wp")))
-        carry = None
+                wplanes.append((kind, bx.or_all(masks, "wp")))
+        ok = subtract(w, wplanes, lambda i, w=w: U(w, i), "s")
         for i in range(B):
-            kind, name = planes[i] if i < nb else ("zero", None)
-            f = lit[kind]
-            src = name if name is not None else H(w, i)
-            last = i == B - 1
-            if carry is None and kind == "reg":      # 4-byte VOP2 forms where the operand needs no complement
-                b.XOR(t(f"s{i}", w), H(w, i), src)
-                if not last:
-                    carry = b.AND(t("c", w), H(w, i), src)
-            elif carry is None:
-                b.BITOP3(t(f"s{i}", w), H(w, i), src, src, lambda h, x, _x, f=f: h ^ f(x))
-                if not last:
-                    carry = b.BITOP3(t("c", w), H(w, i), src, src, lambda h, x, _x, f=f: h & f(x))
-            elif kind == "zero" and last:
-                b.XOR(t(f"s{i}", w), H(w, i), carry)
-            else:
-                b.BITOP3(t(f"s{i}", w), H(w, i), src, carry, lambda h, x, cy, f=f: h ^ f(x) ^ cy)
-                if not last:
-                    carry = b.BITOP3(t("c", w), H(w, i), src, carry,
-                                     lambda h, x, cy, f=f: (h & f(x)) | (h & cy) | (f(x) & cy))
-        # (NOT + nb ANDs — one more instruction, 12 fewer code bytes — measured the same: 29.19 vs 29.24 TCUPS)
-        for i in range(nb):
-            b.BITOP3(t(f"s{i}", w), t(f"s{i}", w), t(f"s{B - 1}", w), t(f"s{B - 1}", w), lambda s, k, _k: s & ~k)
+            b.AND(t(f"s{i}", w), t(f"s{i}", w), ok)
 
-    # ---- -max(W, u): -C at a match, -D at a mismatch with u <= D, else the stored -u ---------------
-    negC, negD = (full + 1 - C) & full, (full + 1 - D) & full
-
-    def seed_planes(w):
+    # ---- max(W, u): C at a match, D at a mismatch with u <= D, else u -------------------------------
+    def max_planes(w):
         for i in range(B):
-            cb, db = 0xFF * ((negC >> i) & 1), 0xFF * ((negD >> i) & 1)
-            b.BITOP3(t(f"g{i}", w), H(w, i), anym[w], E(w),
-                     lambda h, a, e, cb=cb, db=db: (cb & e) | (db & a & ~e) | (h & ~a & ~e))
+            cb, db = 0xFF * ((C >> i) & 1), 0xFF * ((D >> i) & 1)
+            b.BITOP3(t(f"g{i}", w), U(w, i), anym[w], E(w),
+                     lambda u, a, e, cb=cb, db=db: (cb & e) | (db & a & ~e) | (u & ~a & ~e))
 
-    # ---- v one column up: nb shift chains, the seed-plane work interleaved into the first -----------
-    for i in range(nb):
+    # ---- v one column up: B shift chains, the max-plane work interleaved into the first ---------------
+    for i in range(B):
         for w in W:
             (b.ADD_CO if w == 0 else b.ADDC)(t(f"s{i}", w), t(f"s{i}", w), t(f"s{i}", w))
             if i == 0:
-                seed_planes(w)
+                max_planes(w)
 
-    # ---- new -u = g + v_in, clamped at zero from above (a positive sum means u would be negative) --
+    # ---- new u = max(0, max(W, u) - v_in) -------------------------------------------------------------
     for w in W:
-        carry = None
+        ok = subtract(w, [("reg", t(f"g{i}", w)) for i in range(B)], lambda i, w=w: t(f"s{i}", w), "r")
         for i in range(B):
-            last = i == B - 1
-            dst = H(w, i) if last else t(f"r{i}", w)
-            if i < nb:
-                if carry is None:
-                    b.XOR(dst, t(f"g{i}", w), t(f"s{i}", w))
-                    carry = b.AND(t("k", w), t(f"g{i}", w), t(f"s{i}", w))
-                else:
-                    b.BITOP3(dst, t(f"g{i}", w), t(f"s{i}", w), carry, lambda a, b_, c: a ^ b_ ^ c)
-                    carry = b.BITOP3(t("k", w), t(f"g{i}", w), t(f"s{i}", w), carry,
-                                     lambda a, b_, c: (a & b_) | (a & c) | (b_ & c))
-            else:   # the sign plane of v_in is zero
-                b.XOR(dst, t(f"g{i}", w), carry)
-        for i in range(B - 1):
-            b.AND(H(w, i), t(f"r{i}", w), H(w, B - 1))
+            b.AND(U(w, i), t(f"r{i}", w), ok)
     # chains first, their wait states filled with independent work (no extra registers)
     return schedule(b, BITPAL_SCHEDULE_WINDOW) if BITPAL_SCHEDULE_WINDOW else b
 
@@ -1022,7 +1026,7 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
 def bitpal_scores_init_state(nw: int, lanes: int, sc: BitpalScores = BITPAL_DEFAULT, semi: bool = False) -> list:
     """Row 0: every column at dH = G (global), or at dH = 0, i.e. u = -G (semi-global: the
     generator's writeBitInitStr, BitPAlGenerator.java:2201-2218)."""
-    stored = (sc.gap & ((1 << sc.planes) - 1)) if semi else 0       # two's complement of -u
+    stored = -sc.gap if semi else 0                                   # u itself
     return [np.full(lanes, 0xFFFFFFFF if (stored >> i) & 1 else 0, dtype=np.uint32)
             for _ in range(nw) for i in range(sc.planes)]
 
@@ -1097,8 +1101,8 @@ def bitpal_block_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT):
 
 
 def bitpal_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
-    """For the default scores this is the packed kernel of original/BGSA_AVX2/align_core.c:183-428
-    (same five planes, same two's complement of -(dH + 5)) at 75 fast-class VALU per word."""
+    """For the default scores this computes what the packed kernel of original/BGSA_AVX2/align_core.c:
+    183-428 computes (194 ALU operations per word there), on four unsigned planes, in 72 fast-class VALU."""
     return bitpal_scores_body(nw, sc)
 
 

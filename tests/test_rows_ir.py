@@ -222,12 +222,13 @@ def test_bitpal_any_scores_column_blocks(oracle, scores, qlen, slen, nwb):
         assert np.array_equal(R.bitpal_blocked_simulate(s, q[i], nwb, sc), want[i])
 
 
-def test_bitpal_default_scores_are_the_reference_instance():
-    # same planes, chains and instruction count as the body written after align_core.c:183-428
+def test_bitpal_default_scores_instance():
+    # 2/-3/-5: u in 0..12 on four unsigned planes (the reference keeps -u in five, align_core.c:191-214),
+    # five value classes above the mismatch class, thirteen carry chains
     sc = R.BITPAL_DEFAULT
-    assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (5, 13, 12, 7, 5)
-    assert sc.weights() == (-1, -2, -4, -8, 16)
-    assert R.bitpal_body(1).valu_count() == 75
+    assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (4, 13, 12, 7, 5)
+    assert sc.weights() == (1, 2, 4, 8)
+    assert R.bitpal_body(1).valu_count() == 72
 
 
 def test_bitpal_edit_scores_equal_negated_myers(oracle):
