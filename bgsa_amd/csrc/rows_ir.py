@@ -21,7 +21,7 @@ Instruction selection follows scripts/ubench/valu_rate.hip, measured on MI355X:
 Operand count also has a price (scripts/ubench/bank_conflict.hip): a stream of nothing but three-VGPR-
 source v_bitop3 issues at ~2.95 cycles against ~2.27 for two-source VOP2 or for the two alternating;
 the VGPR bank (index mod 4) of the sources makes no difference, a run of 8-byte VOP3 encodings with two
-sources sits in between (~2.6).  In the shipped BitPAl body (49 of 75 instructions three-source) turning
+sources sits in between (~2.6).  In the 75-instruction BitPAl body of the time (49 of them three-source) turning
 every v_bitop3 into a two-source instruction would buy 6.5 %, in the Myers planes body 3 % — the
 instruction count is the lever, so two-source forms are used only where they cost no extra instruction.
 So every 1-bit shift across words is an add-with-carry chain (x + x + carry), every chain goes
