@@ -531,3 +531,40 @@ def test_full_baseline_size_properties(oracle, algo, k, nq, ns, length):
     # the padding reads never alias a real subject: all-'N' against ACGT is all mismatches
     if algo == B.ALGO_MYERS:
         assert bool((scores[:, ns:] == -length).all())
+
+
+# ---- the measurement knobs select alternative kernels; each must give the same scores.  The knobs are
+# read once per process, so every variant runs in a child process (one at a time) ----------------------
+_KNOB_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import bgsa_amd as B, oracle as O
+q = O.gen_reads(901, 3, 310)
+for slen in (150, 310, 700, 1100, 2300):
+    s = O.gen_reads(902 + slen, 130, slen)
+    m = min(310, slen)
+    s[:10, :m] = O.mutate(q[np.arange(10) % 3][:, :m], np.arange(10), 903)
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), O.myers64(q, s)), ("myers", slen)
+    if slen <= 1100:
+        assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL), O.bitpal(q, s)), ("bitpal", slen)
+qb = O.gen_reads(904, 3, 150); sb = O.gen_reads(905, 130, 150); sb[:10] = O.mutate(qb[np.arange(10) % 3], np.arange(10), 906)
+for k in (8, 31):
+    assert np.array_equal(B.align_all_pairs(qb, sb, algo=B.ALGO_BANDED, k=k), O.banded64(qb, sb, k)), ("banded", k)
+print("knobs ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"BGSA_MYERS_IMPL": "c", "BGSA_BITPAL_IMPL": "c", "BGSA_BANDED_IMPL": "c"},
+                                 {"BGSA_MYERS_MAX_PLAIN_WORDS": "8"},
+                                 {"BGSA_MYERS_MAX_PLAIN_WORDS": "8", "BGSA_MYERS_BLOCK_FORM": "planes"},
+                                 {"BGSA_MYERS_PEQ_MAX_WORDS": "8"},
+                                 {"BGSA_BLOCKED_WORKGROUPS": "96"}])
+def test_measurement_knobs_do_not_change_results(env):
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(B.__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, str(root)], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "knobs ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
