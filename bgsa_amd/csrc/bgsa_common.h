@@ -269,6 +269,19 @@ __device__ __forceinline__ void dephase_persistent_workgroup()
     for (int i = 0; i < skew; i++) __builtin_amdgcn_s_sleep(8);             // ~512 cycles each
 }
 
+// Tasks of a column-block kernel are handed out from a device-wide counter (zeroed by the launcher, it
+// sits behind the carry buffers in the workspace): the XCDs do not sustain exactly the same clock, and with
+// a static round-robin the slowest one finished last (average occupancy 96 %; measured +… see DESIGN §4.2).
+__device__ __forceinline__ long long next_blocked_task(unsigned long long *counter)
+{
+    __shared__ unsigned long long s_task;
+    if (threadIdx.x == 0) s_task = atomicAdd(counter, 1ull);
+    __syncthreads();
+    const unsigned long long task = s_task;
+    __syncthreads();   // everyone has read it before thread 0 fetches the next one
+    return static_cast<long long>(task);
+}
+
 inline size_t blocked_carry_bytes(int ref_len, int n_chains)
 {
     return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * blocked_workgroups();

@@ -104,7 +104,7 @@ template <int NW, bool SEMI>
 __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks)
+    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks, unsigned long long *task_counter)
 {
     constexpr int semi = SEMI;
     constexpr int NC = kBitpalChains;
@@ -119,10 +119,10 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
     const int tail_rows = ref_len & 31;
     dephase_persistent_workgroup();
 
-    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    for (long long task = next_blocked_task(task_counter); task < n_tasks; task = next_blocked_task(task_counter)) {
         const int group = __builtin_amdgcn_readfirstlane(static_cast<int>(task / q_tiles) * kWavesPerBlock + wave);
         const int tile = static_cast<int>(task % q_tiles);
-        if (group >= n_groups) continue;  // wave-uniform
+        if (group >= n_groups) continue;  // wave-uniform; the wave still meets the others at the next task fetch
         const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
         const int q0 = tile * q_tile;
         const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
@@ -190,11 +190,14 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     const size_t stream_bytes = (static_cast<size_t>(stride) * nq + 255) & ~static_cast<size_t>(255);
     if (int rc = launch_pack_blocked(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
     uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(
+        reinterpret_cast<unsigned char *>(carry) + blocked_carry_bytes(ref_len, kBitpalChains));
+    BGSA_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
     auto kernel = semi ? bitpal_blocked_kernel<NW, true> : bitpal_blocked_kernel<NW, false>;
     hipLaunchKernelGGL(kernel, dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
-                       stride, n_blocks);
+                       stride, n_blocks, counter);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

@@ -293,7 +293,7 @@ size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queri
     if (read_len > 0 && beyond_registers(algo, (read_len + 31) / 32)) {  // column blocks: streams + carry buffers
         const int chains = algo == BGSA_ALGO_BITPAL ? bitpal_current_set()->chains : 3;  // non-null: beyond_registers() saw it
         const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
-                               blocked_carry_bytes(ref_len, chains);
+                               blocked_carry_bytes(ref_len, chains) + 256;   // + the task counter
         // the A/B state-in-memory kernels (BGSA_MYERS_IMPL=c / BGSA_BITPAL_IMPL=c) keep the DP state here
         const char *ab = getenv(algo == BGSA_ALGO_BITPAL ? "BGSA_BITPAL_IMPL" : "BGSA_MYERS_IMPL");
         const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
