@@ -282,6 +282,15 @@ __device__ __forceinline__ long long next_blocked_task(unsigned long long *count
     return static_cast<long long>(task);
 }
 
+// Queries per task of a column-block kernel: 2, or 1 while that still leaves fewer than 64 tasks per
+// workgroup (the Peq planes are loaded per query and block either way, so a smaller tile costs nothing
+// and shortens the tail of small problems).
+inline int blocked_q_tile(int n_queries, int64_t n_groups)
+{
+    const int64_t tasks = ((n_groups + kWavesPerBlock - 1) / kWavesPerBlock) * ((n_queries + 1) / 2);
+    return tasks < 64 * static_cast<int64_t>(blocked_workgroups()) ? 1 : 2;
+}
+
 inline size_t blocked_carry_bytes(int ref_len, int n_chains)
 {
     return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * blocked_workgroups();

@@ -467,7 +467,8 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     BGSA_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL((myers_blocked_kernel<NW, PEQ>), dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
-                       static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq, 2,
+                       static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
+                       blocked_q_tile(nq, read_count / kLanes),
                        stride, n_blocks, counter);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
