@@ -284,18 +284,26 @@ def main() -> int:
             "config": {"workload": cfg_name + (" [SIZE OVERRIDDEN]" if overridden else ""), "queries": nq,
                        "subjects_per_gpu": ns, "length_bp": length, "k": k, "parallelism": f"subject-sharded x{world}",
                        "kernel": aligner.kernel_name(), "word_num": wn},
+            # The VALU issue roofline.  `achieved` / `frac` count the instructions the shipped row body really
+            # issues (from the generator's own instruction lists) when that is known — the honest utilisation
+            # of the chip; `algorithmic` is the figure of SURVEY §8(d): GCUPS x the REFERENCE's ALU operations
+            # per cell, which exceeds the peak because the kernels need far fewer operations than it counts.
             "roofline": {
                 "bound": "valu",
-                "achieved": round(achieved_ops / 1e12, 3),
+                "basis": "issued" if issued else "reference_op_count",
+                "achieved": issued["achieved"] if issued else round(achieved_ops / 1e12, 3),
                 "peak": round(VALU_PEAK_OPS / 1e12, 2),
                 "unit": "Tops/s",
-                "frac": round(achieved_ops / VALU_PEAK_OPS, 4),
+                "frac": issued["frac"] if issued else round(achieved_ops / VALU_PEAK_OPS, 4),
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
-                "note": "32-bit integer VALU issue bound (SURVEY §8(d)); achieved = GCUPS x the reference's "
-                        f"{ops_cell:.3f} ALU ops/cell (a frac > 1 means the kernel needs fewer ops than the "
-                        "reference counts: see `issued`); kernel time from HIP events on the launch stream",
+                "note": "32-bit integer VALU issue bound (SURVEY §8(d)), peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; "
+                        "kernel time from HIP events on the launch stream",
                 "issued": issued,
+                "algorithmic": {"ops_per_cell": round(ops_cell, 4), "achieved": round(achieved_ops / 1e12, 3),
+                                "frac": round(achieved_ops / VALU_PEAK_OPS, 4),
+                                "note": "GCUPS x the reference's own ALU-op count per cell (SURVEY §8(d)); > 1 = fewer "
+                                        "operations than the reference needs"},
                 "kernel_ms": round(kernel_s * 1e3, 3),
                 "kernel_gcups": round(kernel_gcups, 1),
                 "hbm": {"bound": "hbm", "achieved": round(pairs_per_s * bpp / 1e9, 2), "peak": HBM_PEAK / 1e9,

@@ -3,7 +3,7 @@
 profiles/ under <prefix>_*: bench lines, rocprofv3 kernel stats, per-launch PMC values of the
 dominant kernel, the GPU test log and the microbenchmark outputs.
 
-    python3 scripts/collect_profiles.py gpurun_out/r01_v6 r01_v6
+    python3 scripts/collect_profiles.py gpurun_out/r01_v7 r01_v7
 """
 import csv
 import glob

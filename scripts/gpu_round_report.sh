@@ -1,7 +1,7 @@
 #!/bin/bash
 # Full GPU record for profiles/: tests, the four BASELINE configs with CPU baselines, rocprofv3 stats.
 # Run on the GPU box from the repo root:  bash scripts/gpu_round_report.sh <tag>
-tag=${1:-r01_v6}
+tag=${1:-r01_v7}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
