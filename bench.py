@@ -3,20 +3,29 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
-One "step" = one pass of the hot path over the whole workload: every query against every
-resident subject of this rank (BASELINE.json configs[1] by default: Myers unit-cost global,
-10k queries x 1M subjects, 150 bp).  Inputs (mapped queries, Peq blocks) are resident in HBM
-before the timed region; scores stay in HBM.  For N > 1 the driver launches one rank per GPU
-(torch.distributed / RCCL); subjects are sharded by rank (weak scaling: every rank owns a full
-1M-subject bucket), the query set is broadcast from rank 0 once, and there is no collective in
-the timed region (the reference has none on this path either — SURVEY.md §2a).
+One "step" = one pass of the hot path over the whole workload: every query against every resident
+subject of this rank (BASELINE.json configs[1] by default: Myers unit-cost global, 10k queries x 1M
+subjects, 150 bp).  Inputs (mapped queries, Peq blocks) are resident in HBM before the timed region;
+scores stay in HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed / RCCL):
 
-Prints ONE JSON line (rank 0).  GCUPS = query_len * n_queries * subject_len * n_subjects /
-seconds / 1e9, the reference's formula (original/BGSA_CPU/cal_cpu.c:472).
+  * configs 2-4: weak scaling — every rank owns a full 1M-subject bucket, the query set is broadcast
+    from rank 0 once, no collective in the timed region (the reference has none on this path);
+  * config 5 (BASELINE: "1k x 1M x 1000 bp sharded across 8 MI355X"): strong scaling — ONE 1M-subject
+    bucket cut into contiguous slices with plan_shards (the KNC backend's dispatch_task), so the
+    problem is the same at every N.
+
+`value` is the kernel-path rate (the reference's "cal GCUPS", cal_cpu.c:472); beside it the line carries
+`total_gcups` (raw rows on the host -> scores on the host for reference-sized blocks: H2D + GPU
+preprocess + kernel + D2H, the reference's "Total GCUPS", cal_cpu.c:473-474) and, for N > 1,
+`gather` (the same steps with the per-block score gather to rank 0 over xGMI streamed beside them).
+
+Prints ONE JSON line (rank 0).  GCUPS = query_len * n_queries * subject_len * n_subjects / seconds /
+1e9, the reference's formula (original/BGSA_CPU/cal_cpu.c:472).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -34,13 +43,26 @@ import bgsa_amd as B  # noqa: E402
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz -> 32-bit lane-ops/s (= 157.3 TFLOP/s fp32 / 2)
 VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9
 HBM_PEAK = 8.0e12
+REF_BUCKET_COUNT = 100   # queries per block of the reference's pipeline (original/BGSA_CPU/config.h:13)
 
 CONFIGS = {
-    # id: (algo, name, nq, ns per GPU, length, k, reference ALU ops per (row, word), data bits/word of that count)
-    2: (B.ALGO_MYERS, "Myers unit-cost global, 10k queries x 1M subjects, 150 bp", 10_000, 1_000_000, 150, 0),
-    3: (B.ALGO_BANDED, "Banded Myers e=8, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 8),
-    4: (B.ALGO_BITPAL, "BitPAl packed M=2/I=-3/G=-5, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 0),
-    5: (B.ALGO_MYERS, "Myers multi-word 1000 bp, 1k x 125k subjects per GPU", 1_000, 125_000, 1000, 0),
+    # id: (algo, name, nq, ns, length, k, scaling)
+    2: (B.ALGO_MYERS, "Myers unit-cost global, 10k queries x 1M subjects, 150 bp", 10_000, 1_000_000, 150, 0, "weak"),
+    3: (B.ALGO_BANDED, "Banded Myers e=8, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 8, "weak"),
+    4: (B.ALGO_BITPAL, "BitPAl packed M=2/I=-3/G=-5, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 0, "weak"),
+    5: (B.ALGO_MYERS, "Myers multi-word 1000 bp, 1k queries x 1M subjects sharded over the GPUs", 1_000, 1_000_000, 1000, 0, "strong"),
+}
+
+# Subject mixes of the banded filter (config 3).  Its work is data dependent: a wave stops as soon as every
+# one of its 64 lanes is past the error limit, so the rate depends on how many pairs survive and how they
+# are spread over waves.
+BANDED_MIXES = {
+    "planted": "SURVEY 8(d): uniform random reads, 1 % of the subjects near-duplicates (0..k edits) of one query each",
+    "random": "uniform random pairs only: every wave stops at its first test",
+    "dense1pct": "1 % of ALL PAIRS survive: every query is within 2 edits of one ancestor and 1 % of the subjects, "
+                 "scattered, within k-3 edits of it — 1 - 0.99^64 = 47 % of the waves hold a surviving lane",
+    "survivors": "every pair survives (all reads within a few edits of one ancestor): no early exit at all, "
+                 "the nominal work of the full matrix",
 }
 
 
@@ -54,14 +76,14 @@ def algorithmic_ops_per_cell(algo: int, length: int, k: int) -> float:
     return 42.0 / length  # banded: 42 ops per row, nominal full-matrix cells
 
 
-def algorithmic_bytes_per_pair(algo: int, length: int, wn: int, q_tile: int = 100) -> float:
+def algorithmic_bytes_per_pair(algo: int, length: int, wn: int, q_tile: int = REF_BUCKET_COUNT) -> float:
     """score bytes + Peq bytes amortised over a query tile of REF_BUCKET_COUNT."""
     out = 1 if algo == B.ALGO_BANDED else 2
     peq = B.group_words(algo, wn, 8) * 4 / 64
     return out + peq / q_tile
 
 
-def issued_valu_per_row(algo: int, wn: int, scores=None):
+def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
     """VALU instructions the shipped row body issues per (query row, wave), from the generator's
     own instruction lists (bgsa_amd/csrc/rows_ir.py); None for the compiler-scheduled kernels."""
     sys.path.insert(0, str(ROOT / "bgsa_amd" / "csrc"))
@@ -77,22 +99,21 @@ def issued_valu_per_row(algo: int, wn: int, scores=None):
         return R.myers_planes_body(nw).valu_count()
     if algo == B.ALGO_BITPAL and wn <= 8:
         return R.bitpal_body(wn, R.BitpalScores(*scores) if scores else R.BITPAL_DEFAULT).valu_count()
+    if algo == B.ALGO_BANDED:                  # per row that is actually run (early exit: fewer rows than nominal)
+        return (R.banded_body() if k <= 15 else R.banded_body64()).valu_count()
     return None
 
 
-def pmc_traffic(config: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc.csv): separate
-    FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md §HBM (it tallies 128-B requests at 64 B)."""
+def pmc_values(config: int, tag: str = ""):
+    """Per-launch counter values of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*cfg<N><tag>_pmc.csv: separate --pmc runs of this same command, scripts/collect_profiles.py)."""
     import csv
     import glob
-    files = sorted(glob.glob(str(ROOT / "profiles" / f"*cfg{config}_pmc.csv")))
+    files = sorted(glob.glob(str(ROOT / "profiles" / f"*cfg{config}{tag}_pmc.csv")))
     if not files:
-        return None
+        return None, None
     vals = {r["counter"]: float(r["value_per_launch"]) for r in csv.DictReader(open(files[-1]))}
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return {"bytes": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024, "source": Path(files[-1]).name}
+    return vals, Path(files[-1]).name
 
 
 def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> dict:
@@ -134,6 +155,107 @@ def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> d
     return {"value": cells / secs / 1e9, "unit": "GCUPS", "cores": threads, "kind": "port", "impl": impl, "sample": sample}
 
 
+# ---- synthetic reads ---------------------------------------------------------------------------------
+
+def random_reads(n, length, gen, dev):
+    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    return letters[torch.randint(0, 4, (n, length), generator=gen, device=dev)]
+
+
+def mutate_reads(rows, max_edits, gen, dev):
+    """Up to max_edits substitutions per read (uniform count 0..max_edits), on the GPU.  Substitutions
+    keep the length — what the banded kernel needs (equal lengths only) — and bound the edit distance."""
+    n, length = rows.shape
+    out = rows.clone()
+    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    n_edits = torch.randint(0, max_edits + 1, (n,), generator=gen, device=dev)
+    for e in range(max_edits):
+        pos = torch.randint(0, length, (n,), generator=gen, device=dev)
+        new = letters[torch.randint(0, 4, (n,), generator=gen, device=dev)]
+        idx = torch.nonzero(n_edits > e).squeeze(1)
+        out[idx, pos[idx]] = new[idx]
+    return out
+
+
+def make_workload(config, algo, nq, ns, length, k, mix, rank, dev, dist):
+    """Queries [nq, length] and subject rows [ns_pad, length+1] (uint8 device tensors)."""
+    ns_pad = (ns + 63) // 64 * 64
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xB65A0000 + config)
+    q_rows = random_reads(nq, length, gen, dev)
+    ancestor = None
+    if algo == B.ALGO_BANDED and mix in ("dense1pct", "survivors"):
+        ancestor = random_reads(1, length, gen, dev)
+        q_rows = mutate_reads(ancestor.expand(nq, length), 2, gen, dev)
+    if dist is not None:
+        dist.broadcast(q_rows, src=0)  # C1 of SURVEY §2a: every device sees all queries
+        if ancestor is not None:
+            dist.broadcast(ancestor, src=0)
+    gen.manual_seed(0xB65A1000 + config + 7919 * rank)
+    s_rows = torch.full((ns_pad, length + 1), ord("\n"), dtype=torch.uint8, device=dev)
+    s_rows[:, :length] = ord("N")  # padding reads, as the reference pads the last bucket (file.c:98-112)
+    s_rows[:ns, :length] = random_reads(ns, length, gen, dev)
+    if algo == B.ALGO_BANDED and mix != "random":
+        if mix == "survivors":
+            s_rows[:ns, :length] = mutate_reads(ancestor.expand(ns, length), max(k - 3, 1), gen, dev)
+        else:
+            n_planted = ns // 100
+            where = torch.randperm(ns, generator=gen, device=dev)[:n_planted]
+            if mix == "planted":   # near-duplicates of individual queries
+                src = q_rows[torch.randint(0, nq, (n_planted,), generator=gen, device=dev)]
+                s_rows[where, :length] = mutate_reads(src, k, gen, dev)
+            else:                  # dense1pct: near the common ancestor of all queries
+                s_rows[where, :length] = mutate_reads(ancestor.expand(n_planted, length), max(k - 3, 1), gen, dev)
+    return q_rows, s_rows, ns_pad
+
+
+# ---- Total GCUPS: host rows -> host scores for reference-sized blocks ---------------------------------
+
+def total_gcups_leg(algo, k, scores, q_host, s_rows_dev, ns, ns_pad, length, dev, n_blocks=10):
+    """Raw subject rows in pinned host memory -> H2D -> GPU preprocess -> per block of REF_BUCKET_COUNT
+    queries: kernel on one stream, D2H of the previous block's scores on another (two result buffers) ->
+    scores in pinned host memory.  Wall time of all of it = the reference's Total GCUPS
+    (cal_cpu.c:473-474) without the file I/O (the reference keeps that outside too: its I/O threads)."""
+    L = B.lib()
+    nq = min(q_host.shape[0], n_blocks * REF_BUCKET_COUNT)
+    n_blocks = (nq + REF_BUCKET_COUNT - 1) // REF_BUCKET_COUNT
+    esz = 1 if algo == B.ALGO_BANDED else 2
+    h_rows = torch.empty(s_rows_dev.numel(), dtype=torch.uint8).pin_memory()
+    h_rows.copy_(s_rows_dev.reshape(-1))
+    h_out = [torch.empty((REF_BUCKET_COUNT, ns_pad), dtype=torch.int8 if esz == 1 else torch.int16).pin_memory() for _ in range(2)]
+    a = B.DeviceAligner(algo, str(dev), k, scores)
+    d_rows = torch.empty_like(s_rows_dev.reshape(-1))
+    d_out = [torch.empty((REF_BUCKET_COUNT, ns_pad), dtype=a.out_dtype, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    done = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    a.set_queries(q_host[:nq])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d_rows.copy_(h_rows, non_blocking=True)
+    a.set_subject_rows_device(d_rows, ns_pad, length, qlen=length)
+    for b in range(n_blocks):
+        slot = b & 1
+        lo, hi = b * REF_BUCKET_COUNT, min(nq, (b + 1) * REF_BUCKET_COUNT)
+        if b >= 2:
+            torch.cuda.current_stream(dev).wait_event(copied[slot])   # the buffer's previous copy-out is done
+        a.score(lo, hi, out=d_out[slot][: hi - lo])
+        done[slot].record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done[slot])
+            h_out[slot][: hi - lo].copy_(d_out[slot][: hi - lo], non_blocking=True)
+            copied[slot].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    a.check_faults()
+    cells = float(nq) * ns * length * length
+    return {"value": round(cells / wall / 1e9, 1), "unit": "GCUPS", "wall_ms": round(wall * 1e3, 2),
+            "what": f"{n_blocks} blocks of {REF_BUCKET_COUNT} queries x {ns_pad} subjects: pinned host rows -> H2D -> GPU "
+                    f"preprocess -> kernel -> D2H (double-buffered on a second stream) -> pinned host scores; "
+                    f"formula of cal_cpu.c:473-474 without the file I/O",
+            "h2d_bytes": int(h_rows.numel()), "d2h_bytes": int(nq * ns_pad * esz)}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,11 +263,17 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--nq", type=int, default=None, help="override query count (not the BASELINE config)")
-    ap.add_argument("--ns", type=int, default=None, help="override subjects per GPU (not the BASELINE config)")
+    ap.add_argument("--ns", type=int, default=None, help="override subject count (not the BASELINE config)")
     ap.add_argument("--length", type=int, default=None, help="override read length (not the BASELINE config)")
+    ap.add_argument("--k", type=int, default=None, help="override the banded threshold (not the BASELINE config)")
     ap.add_argument("--scores", type=str, default=None,
                     help="match,mismatch,gap for config 4 (BitPAl); any set other than 2,-3,-5 is not a BASELINE config")
+    ap.add_argument("--banded-mix", type=str, default="planted", choices=sorted(BANDED_MIXES),
+                    help="subject mix of config 3 (default: SURVEY 8(d)'s planted stratum)")
+    ap.add_argument("--banded-variants", type=str, default="random,dense1pct,survivors",
+                    help="config 3, one GPU: other mixes timed after the main one ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-total", action="store_true", help="skip the Total-GCUPS leg")
     ap.add_argument("--cpu-sample", type=str, default="2000x100000", help="queries x subjects timed on the CPU")
     args = ap.parse_args()
 
@@ -165,40 +293,37 @@ def main() -> int:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    algo, cfg_name, nq, ns, length, k = CONFIGS[args.config]
+    algo, cfg_name, nq, ns_total, length, k, scaling = CONFIGS[args.config]
     scores = tuple(int(x) for x in args.scores.split(",")) if args.scores else None
     if scores is not None and algo != B.ALGO_BITPAL:
         print("[bench] --scores only applies to --config 4", file=sys.stderr)
         return 2
     custom_scores = scores is not None and scores != (2, -3, -5)
-    overridden = args.nq is not None or args.ns is not None or args.length is not None or custom_scores
+    overridden = any(x is not None for x in (args.nq, args.ns, args.length, args.k)) or custom_scores
     if custom_scores:
         cfg_name = f"BitPAl packed M={scores[0]}/I={scores[1]}/G={scores[2]}, 10k x 1M, 150 bp"
     nq = args.nq or nq
-    ns = args.ns or ns
+    ns_total = args.ns or ns_total
     length = args.length or length
-    ns_pad = (ns + 63) // 64 * 64
+    k = args.k if args.k is not None else k
+    mix = args.banded_mix if algo == B.ALGO_BANDED else None
 
-    # ---- synthetic workload: uniform i.i.d. A/C/G/T, generated on the GPU -------------------------
-    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0xB65A0000 + args.config)
-    q_rows = letters[torch.randint(0, 4, (nq, length), generator=gen, device=dev)]
-    if dist is not None:
-        dist.broadcast(q_rows, src=0)  # C1 of SURVEY §2a: every device sees all queries
-    gen.manual_seed(0xB65A1000 + args.config + 7919 * rank)
-    s_rows = torch.full((ns_pad, length + 1), ord("\n"), dtype=torch.uint8, device=dev)
-    s_rows[:, :length] = ord("N")  # padding reads, as the reference pads the last bucket (file.c:98-112)
-    s_rows[:ns, :length] = letters[torch.randint(0, 4, (ns, length), generator=gen, device=dev)]
+    # ---- this rank's subjects -----------------------------------------------------------------------------
+    from bgsa_amd.multi_gpu import ScoreGatherStream, plan_shards
+    if scaling == "strong":
+        shards = plan_shards(ns_total, world)        # one bucket, contiguous slices (dispatch_task)
+        ns = shards[rank].count
+    else:
+        shards = None
+        ns = ns_total                                # every rank its own full bucket
+    q_rows, s_rows, ns_pad = make_workload(args.config, algo, nq, ns, length, k, mix, rank, dev, dist)
 
     aligner = B.DeviceAligner(algo, f"cuda:{local_rank}", k, scores if algo == B.ALGO_BITPAL else None)
-    aligner.set_queries(q_rows.cpu().numpy())
+    q_host = q_rows.cpu().numpy()
+    aligner.set_queries(q_host)
     aligner.set_subject_rows_device(s_rows.reshape(-1), ns_pad, length, qlen=length)
     out = torch.empty((nq, ns_pad), dtype=aligner.out_dtype, device=dev)
     torch.cuda.synchronize()
-
-    def step():
-        aligner.score(0, nq, out=out)
 
     def fence():
         torch.cuda.synchronize()
@@ -206,68 +331,93 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev0[i].record()
-        step()
-        ev1[i].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
-    kernel_s = float(np.mean(kernel_ms)) / 1e3
+    def timed(step_fn, steps, warmup):
+        """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; wall time =
+        max over ranks; kernel time = HIP events on the launch stream around each step."""
+        for _ in range(warmup):
+            step_fn()
+        fence()
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev0[i].record()
+            step_fn()
+            ev1[i].record()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) / 1e3
 
-    # size-independent sanity on the full-size output: diagonal-free checksum properties
+    elapsed, kernel_s = timed(lambda: aligner.score(0, nq, out=out), args.steps, args.warmup)
+    aligner.check_faults()
+
+    # size-independent sanity on the full-size output
     checksum = int(out[:, :ns].to(torch.int64).sum().item()) if rank == 0 else 0
+    survivors = int((out[:, :ns] != 127).sum().item()) if (rank == 0 and algo == B.ALGO_BANDED) else None
 
-    # Outside the timed region, N > 1 only: the score gather of SURVEY §2a C3 — every rank's
-    # [REF_BUCKET_COUNT, subjects] tile to rank 0 over xGMI (RCCL), timed once for the record.
+    # ---- N > 1: the same steps with the score gather of SURVEY §2a C3 streamed beside them -------------------
     gather_info = None
     if dist is not None and world > 1:
         try:
-            from bgsa_amd.multi_gpu import Shard, ShardedAligner
-            sa = ShardedAligner(dist=dist, device=dev, score_fn=lambda *_: None, algo=algo, k=k)
-            tile = out[:100, :ns].contiguous()
-            shards = [Shard(r * ns, ns) for r in range(world)]
-            fence()
-            g0 = time.perf_counter()
-            gathered = sa.gather_scores(tile, shards, layout="row_major")
-            fence()
-            g1 = time.perf_counter()
-            if rank == 0:
-                ok = bool((gathered[:, :ns] == tile).all())
-                gather_info = {"what": "100-query score tiles of all ranks to rank 0 (RCCL gather, outside the timed steps)",
-                               "bytes_per_rank": int(tile.numel() * tile.element_size()), "ms": round((g1 - g0) * 1e3, 3),
-                               "rank0_tile_intact": ok}
-            del gathered
+            all_shards = shards if shards is not None else [type("S", (), {"start": r * ns, "count": ns})() for r in range(world)]
+            gs = ScoreGatherStream(dist, dev, [s.count for s in all_shards], aligner.out_dtype, block_rows=REF_BUCKET_COUNT)
+            nq_g = min(nq, 10 * REF_BUCKET_COUNT)     # ten reference-sized blocks are enough to see the steady state
+
+            def gather_step():
+                for lo in range(0, nq_g, REF_BUCKET_COUNT):
+                    hi = min(nq_g, lo + REF_BUCKET_COUNT)
+                    aligner.score(lo, hi, out=out[lo:hi])
+                    gs.submit(out[lo:hi, :ns])
+                gs.drain()
+
+            g_elapsed, _ = timed(gather_step, 1, 1)
+            k_elapsed, _ = timed(lambda: [aligner.score(lo, min(nq_g, lo + REF_BUCKET_COUNT), out=out[lo:lo + REF_BUCKET_COUNT])
+                                          for lo in range(0, nq_g, REF_BUCKET_COUNT)], 1, 1)
+            cells_g = float(nq_g) * (ns_total if scaling == "strong" else ns * world) * length * length
+            gather_info = {"what": f"{(nq_g + REF_BUCKET_COUNT - 1) // REF_BUCKET_COUNT} blocks of {REF_BUCKET_COUNT} queries: kernel per "
+                                   f"block, tiles of all ranks to rank 0 in the reference's per-device block layout "
+                                   f"(cal_mic.c:535-536), grouped send/recv on a side stream, double-buffered",
+                           "gcups_with_gather": round(cells_g / g_elapsed / 1e9, 1),
+                           "gcups_kernels_only_same_blocks": round(cells_g / k_elapsed / 1e9, 1),
+                           "bytes_to_root_per_block": int(sum(s.count for s in all_shards[1:]) * REF_BUCKET_COUNT * out.element_size()),
+                           "root_blocks_checked": gs.blocks_checked}
         except Exception as e:  # never let the optional leg break the benchmark line
             gather_info = {"error": repr(e)}
 
+    n_subjects_job = ns_total if scaling == "strong" else ns * world
     cells_per_step_rank = float(nq) * ns * length * length
-    gcups = cells_per_step_rank * world * args.steps / elapsed / 1e9
-    result = None
+    cells_per_step_job = float(nq) * n_subjects_job * length * length
+    gcups = cells_per_step_job * args.steps / elapsed / 1e9
     if rank == 0:
         wn = aligner.wn
         ops_cell = algorithmic_ops_per_cell(algo, length, k)
         kernel_gcups = cells_per_step_rank / kernel_s / 1e9
         achieved_ops = kernel_gcups * 1e9 * ops_cell
-        pairs_per_s = float(nq) * ns / kernel_s
+        pairs_per_launch = float(nq) * ns_pad
         bpp = algorithmic_bytes_per_pair(algo, length, wn)
-        vpr = issued_valu_per_row(algo, wn, scores)
+        vpr = issued_valu_per_row(algo, wn, k, scores)
+        pmc, pmc_src = pmc_values(args.config, f"_{mix}" if mix else "") if not overridden else (None, None)
+        wave_rows = float(nq) * (ns_pad // 64) * length          # nominal (query row, wave) pairs per launch
         issued = None
-        if vpr:
-            issued_ops = vpr * 64.0 * (float(nq) * (ns_pad // 64) * length) / kernel_s
-            issued = {"valu_per_row": vpr, "achieved": round(issued_ops / 1e12, 2), "unit": "Tops/s",
-                      "frac": round(issued_ops / VALU_PEAK_OPS, 4)}
-        traffic = pmc_traffic(args.config) if not overridden else None
+        if pmc and "SQ_INSTS_VALU" in pmc:                       # measured: the counter of the same command
+            ops = pmc["SQ_INSTS_VALU"] * 64.0 / kernel_s
+            issued = {"source": f"SQ_INSTS_VALU, {pmc_src}", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
+                      "valu_per_nominal_wave_row": round(pmc["SQ_INSTS_VALU"] / wave_rows, 3),
+                      "achieved": round(ops / 1e12, 2), "unit": "Tops/s", "frac": round(ops / VALU_PEAK_OPS, 4)}
+        elif vpr and not (algo == B.ALGO_BANDED and mix != "survivors"):   # exact when no wave exits early
+            ops = vpr * 64.0 * wave_rows / kernel_s
+            issued = {"source": "generator instruction lists (rows_ir.py) x rows x waves", "valu_per_row": vpr,
+                      "achieved": round(ops / 1e12, 2), "unit": "Tops/s", "frac": round(ops / VALU_PEAK_OPS, 4)}
+        traffic = None
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM (128-B requests tallied at 64 B); KB units
+            traffic = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024
+        algorithmic_bytes = pairs_per_launch * bpp
+        frac = achieved_ops / VALU_PEAK_OPS
         result = {
             "metric": "GCUPS (cell updates/sec) all-pairs Myers 150bp" if args.config == 2 else f"GCUPS ({cfg_name})",
             "value": round(gcups, 2),
@@ -277,43 +427,90 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": cfg_name + (" [SIZE OVERRIDDEN]" if overridden else ""), "queries": nq,
-                       "subjects_per_gpu": ns, "length_bp": length, "k": k, "parallelism": f"subject-sharded x{world}",
+                       "subjects_total": n_subjects_job, "subjects_this_rank": ns, "length_bp": length, "k": k,
+                       "parallelism": f"subject-sharded x{world} ({scaling} scaling)",
                        "kernel": aligner.kernel_name(), "word_num": wn},
-            # The VALU issue roofline.  `achieved` / `frac` count the instructions the shipped row body really
-            # issues (from the generator's own instruction lists) when that is known — the honest utilisation
-            # of the chip; `algorithmic` is the figure of SURVEY §8(d): GCUPS x the REFERENCE's ALU operations
-            # per cell, which exceeds the peak because the kernels need far fewer operations than it counts.
+            # The roofline that binds this path is the 32-bit integer VALU issue rate.  `achieved` /
+            # `frac` are §8(d)'s figure: GCUPS x the REFERENCE's own ALU operations per cell.  It may exceed 1: the
+            # kernels need fewer operations per cell than the reference counts (`ops_note`); `issued` is the
+            # utilisation of the chip — VALU instructions really issued x 64 lanes / time / peak — and is <= 1.
             "roofline": {
                 "bound": "valu",
-                "basis": "issued" if issued else "reference_op_count",
-                "achieved": issued["achieved"] if issued else round(achieved_ops / 1e12, 3),
+                "basis": "reference_op_count (SURVEY 8(d))",
+                "achieved": round(achieved_ops / 1e12, 3),
                 "peak": round(VALU_PEAK_OPS / 1e12, 2),
                 "unit": "Tops/s",
-                "frac": issued["frac"] if issued else round(achieved_ops / VALU_PEAK_OPS, 4),
-                "traffic": traffic["bytes"] if traffic else None,
-                "traffic_source": traffic["source"] if traffic else None,
-                "note": "32-bit integer VALU issue bound (SURVEY §8(d)), peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; "
-                        "kernel time from HIP events on the launch stream",
+                "frac": round(frac, 4),
+                "ops_per_cell_reference": round(ops_cell, 4),
+                "ops_note": None,
                 "issued": issued,
-                "algorithmic": {"ops_per_cell": round(ops_cell, 4), "achieved": round(achieved_ops / 1e12, 3),
-                                "frac": round(achieved_ops / VALU_PEAK_OPS, 4),
-                                "note": "GCUPS x the reference's own ALU-op count per cell (SURVEY §8(d)); > 1 = fewer "
-                                        "operations than the reference needs"},
+                "traffic": traffic,
+                "traffic_source": pmc_src if traffic else None,
+                "algorithmic_bytes": round(algorithmic_bytes),
+                "traffic_ratio": round(traffic / algorithmic_bytes, 2) if traffic else None,
                 "kernel_ms": round(kernel_s * 1e3, 3),
                 "kernel_gcups": round(kernel_gcups, 1),
-                "hbm": {"bound": "hbm", "achieved": round(pairs_per_s * bpp / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": round(pairs_per_s * bpp / HBM_PEAK, 6),
-                        "bytes_per_pair": round(bpp, 3)},
+                "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; kernel time from HIP events on the launch stream; "
+                        "traffic_ratio > 1: the kernels tile 32 queries per Peq load where SURVEY's byte model assumes 100",
+                "hbm": {"bound": "hbm", "achieved": round(algorithmic_bytes / kernel_s / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": round(algorithmic_bytes / kernel_s / HBM_PEAK, 6),
+                        "bytes_per_pair": round(bpp, 3),
+                        "measured_gbps": round(traffic / kernel_s / 1e9, 2) if traffic else None},
             },
             "checksum": checksum,
         }
+        if issued and frac > 1:
+            per_cell = issued["achieved"] * 1e12 / (kernel_gcups * 1e9)
+            result["roofline"]["ops_note"] = (f"frac > 1 is not skipped work: the kernel issues {per_cell:.3f} lane-ops per cell where the "
+                                              f"reference counts {ops_cell:.3f} (v_bitop3 + VCC carry chains + 32 data bits per word)")
+        if algo == B.ALGO_BANDED:
+            result["config"]["banded_mix"] = {"name": mix, "what": BANDED_MIXES[mix],
+                                              "pairs_not_rejected": survivors, "fraction": survivors / (float(nq) * ns)}
         if gather_info:
             result["gather"] = gather_info
+
+    # ---- config 3, one GPU: the other subject mixes (same kernel, same sizes) ---------------------------------
+    if algo == B.ALGO_BANDED and world == 1 and args.banded_variants and not overridden:
+        variants = {}
+        for name in [v for v in args.banded_variants.split(",") if v and v != mix]:
+            del s_rows
+            torch.cuda.empty_cache()
+            vq, s_rows, _ = make_workload(args.config, algo, nq, ns, length, k, name, rank, dev, None)
+            aligner.set_queries(vq.cpu().numpy())
+            aligner.set_subject_rows_device(s_rows.reshape(-1), ns_pad, length, qlen=length)
+            _, v_kernel_s = timed(lambda: aligner.score(0, nq, out=out), args.steps, 1)
+            aligner.check_faults()
+            v = {"what": BANDED_MIXES[name], "kernel_ms": round(v_kernel_s * 1e3, 3),
+                 "gcups": round(cells_per_step_rank / v_kernel_s / 1e9, 1),
+                 "pairs_not_rejected_fraction": float((out[:, :ns] != 127).sum().item()) / (float(nq) * ns)}
+            vp, vsrc = pmc_values(args.config, f"_{name}")
+            if vp and "SQ_INSTS_VALU" in vp:
+                v["issued_frac"] = round(vp["SQ_INSTS_VALU"] * 64.0 / v_kernel_s / VALU_PEAK_OPS, 4)
+                v["issued_source"] = f"SQ_INSTS_VALU, {vsrc}"
+            elif name == "survivors":
+                v["issued_frac"] = round(issued_valu_per_row(algo, aligner.wn, k) * 64.0 * float(nq) * (ns_pad // 64) * length
+                                         / v_kernel_s / VALU_PEAK_OPS, 4)
+                v["issued_source"] = "generator instruction lists x all rows (no wave exits early in this mix)"
+            variants[name] = v
+        result["banded_variants"] = variants
+        # restore the main mix for the legs below
+        q_rows, s_rows, _ = make_workload(args.config, algo, nq, ns, length, k, mix, rank, dev, None)
+        q_host = q_rows.cpu().numpy()
+
+    if rank == 0:
+        if not args.no_total and world == 1:
+            try:
+                del out
+                torch.cuda.empty_cache()
+                result["total_gcups"] = total_gcups_leg(algo, k, scores if algo == B.ALGO_BITPAL else None, q_host,
+                                                        s_rows, ns, ns_pad, length, dev)
+            except Exception as e:
+                result["total_gcups"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and not custom_scores:  # the reference commits 2/-3/-5 only
             cq, cs = (int(x) for x in args.cpu_sample.split("x"))
             cq, cs = min(cq, nq), min(cs, ns) // 8 * 8

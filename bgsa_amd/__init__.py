@@ -25,6 +25,12 @@ V_NUM = 64
 _lib = None
 
 
+class Params(ctypes.Structure):
+    """bgsa_hip_params_t of include/bgsa_hip.h: everything a scoring call reads, as one value."""
+    _fields_ = [("algo", ctypes.c_int), ("alignment", ctypes.c_int), ("match", ctypes.c_int),
+                ("mismatch", ctypes.c_int), ("gap", ctypes.c_int), ("k", ctypes.c_int)]
+
+
 class BgsaHipError(RuntimeError):
     pass
 
@@ -75,6 +81,24 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_cal_align_score_dev.argtypes = [i32, vp, vp, vp, i32, i32, i64, i32, i32, i32, i32, vp, sz, vp]
     L.bgsa_hip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.bgsa_hip_workspace_bytes.restype = sz
+    pp = ctypes.POINTER(Params)
+    L.bgsa_hip_current_params.argtypes = [pp]
+    L.bgsa_hip_workspace_bytes_ex.argtypes = [pp, i32, i32, i32]
+    L.bgsa_hip_workspace_bytes_ex.restype = sz
+    L.bgsa_hip_cal_align_score_ex.argtypes = [pp, vp, vp, vp, i32, i32, i64, i32, i32, i32, vp, sz, vp]
+    L.bgsa_hip_stream_faults.argtypes = [i32]
+    L.bgsa_hip_debug_inject_stream_fault.argtypes = [i32]
+    L.bgsa_hip_set_auto_resident.argtypes = [i32]
+    L.bgsa_hip_bucket_resident.argtypes = [vp, sz, i32]
+    L.bgsa_hip_bucket_release.argtypes = [vp]
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.bgsa_hip_seam_stats.argtypes = [u64p, u64p, u64p]
+    L.bgsa_hip_event_create.argtypes = [ctypes.POINTER(vp)]
+    L.bgsa_hip_event_destroy.argtypes = [vp]
+    L.bgsa_hip_event_record.argtypes = [vp, vp]
+    L.bgsa_hip_event_synchronize.argtypes = [vp]
+    L.bgsa_hip_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.bgsa_hip_stream_wait_event.argtypes = [vp, vp]
     L.bgsa_hip_query_stream.argtypes = [i32, vp, i32, i32, vp, i32]
     L.bgsa_hip_kernel_name.argtypes = [i32, i32]
     L.bgsa_hip_kernel_name.restype = ctypes.c_char_p
@@ -224,24 +248,42 @@ class DeviceAligner:
                                               self.ns, self.wn, self.k, self.d_peq.data_ptr(),
                                               self._stream()), "handle_reads_dev")
 
+    def params(self) -> Params:
+        """This aligner's own scoring parameters (the *_ex entry points take them explicitly, so two
+        aligners with different scores or modes never meet in the C ABI's process-global ints)."""
+        if self.algo == ALGO_BITPAL:
+            m, x, g = self.scores or (2, -3, -5)
+        elif self.algo == ALGO_MYERS and self.scores == (0, 1, 1):
+            m, x, g = 0, 1, 1            # generator -m 1: +distance
+        else:
+            m, x, g = 0, -1, -1
+        return Params(self.algo, 1 if self.semi_global else 0, m, x, g, self.k)
+
     def score(self, ref_start: int = 0, ref_end: int | None = None, out=None):
         """Scores queries [ref_start, ref_end) against the resident bucket -> [nq_tile, ns] tensor."""
         torch = self.torch
         ref_end = self.nq if ref_end is None else ref_end
         if out is None:
             out = torch.empty((ref_end - ref_start, self.ns), dtype=self.out_dtype, device=self.device)
-        self._select()
-        need = int(lib().bgsa_hip_workspace_bytes(self.algo, self.qlen, self.slen, ref_end - ref_start))
+        p = self.params()
+        need = int(lib().bgsa_hip_workspace_bytes_ex(ctypes.byref(p), self.qlen, self.slen, ref_end - ref_start))
         if getattr(self, "d_work", None) is None or self.d_work.numel() < need:
             self.d_work = torch.empty(max(need, 8), dtype=torch.uint8, device=self.device)
-        check(lib().bgsa_hip_cal_align_score_dev(self.algo, self.d_content.data_ptr(), self.d_peq.data_ptr(),
-                                                 out.data_ptr(), self.qlen, self.slen, self.ns, ref_start,
-                                                 ref_end, self.wn, self.k, self.d_work.data_ptr(),
-                                                 self.d_work.numel(), self._stream()), "cal_align_score_dev")
+        check(lib().bgsa_hip_cal_align_score_ex(ctypes.byref(p), self.d_content.data_ptr(), self.d_peq.data_ptr(),
+                                                out.data_ptr(), self.qlen, self.slen, self.ns, ref_start,
+                                                ref_end, self.wn, self.d_work.data_ptr(),
+                                                self.d_work.numel(), self._stream()), "cal_align_score_ex")
         return out
 
+    def check_faults(self) -> None:
+        """Synchronises and raises if a kernel reported a stream fault (bgsa_hip_stream_faults)."""
+        self.torch.cuda.synchronize(self.device)
+        flags = int(lib().bgsa_hip_stream_faults(1))
+        if flags:
+            raise BgsaHipError(f"stream fault: {lib().bgsa_hip_last_error().decode()}")
+
     def _select(self) -> None:
-        # the score set and the alignment mode are process-global state of the C ABI (the reference's ints)
+        # the process-global selection of the C ABI (the reference's ints), for the entry points that read it
         if self.algo == ALGO_BITPAL:
             check(lib().bgsa_hip_select_scores(*(self.scores or (2, -3, -5))), "select_scores")
         elif self.algo == ALGO_MYERS and self.scores == (0, 1, 1):
@@ -252,7 +294,9 @@ class DeviceAligner:
 
     def kernel_name(self) -> str:
         self._select()
-        return lib().bgsa_hip_kernel_name(self.algo, self.wn).decode()
+        name = lib().bgsa_hip_kernel_name(self.algo, self.wn).decode()
+        lib().bgsa_hip_select_alignment(0)
+        return name
 
 
 def align_all_pairs(queries: np.ndarray, subjects: np.ndarray, algo: int = ALGO_MYERS, k: int = 0,
@@ -262,4 +306,5 @@ def align_all_pairs(queries: np.ndarray, subjects: np.ndarray, algo: int = ALGO_
     a.set_queries(queries)
     a.set_subjects(subjects)
     out = a.score()
+    a.check_faults()
     return out[:, : a.ns_real].cpu().numpy()

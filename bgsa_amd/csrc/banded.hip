@@ -168,7 +168,8 @@ namespace { int banded_impl(); }
 template <bool WIDE>
 __global__ __launch_bounds__(256) void banded_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
-    long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes)
+    long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
+    unsigned *__restrict__ fault_word)
 {
     constexpr int NM = WIDE ? 4 : 3;  // resident 32-bit words per class, the last one is the prefetch target
     const int lane = threadIdx.x & (kLanes - 1);
@@ -208,18 +209,20 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
         unsigned long long dead_mask;
         unsigned long long vp, vn;
         uint32_t acc;
+        int left;
         if constexpr (WIDE) {
             dead_mask = banded_rows_asm64(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band),
-                                          static_cast<uint32_t>(band >> 32), limit);
+                                          static_cast<uint32_t>(band >> 32), limit, left);
             vp = st[0] | (static_cast<unsigned long long>(st[1]) << 32);
             vn = st[2] | (static_cast<unsigned long long>(st[3]) << 32);
             acc = st[4];
         } else {
-            dead_mask = banded_rows_asm32(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band), 0u, limit);
+            dead_mask = banded_rows_asm32(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band), 0u, limit, left);
             vp = st[0];
             vn = st[1];
             acc = st[2];
         }
+        note_stream_fault(fault_word, left);
         const bool dead = (dead_mask >> lane) & 1ull;
         int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
         if (dead_mask != ~0ull) {
@@ -262,14 +265,16 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     }
     if (int rc = launch_pack_banded(d_content, len, k, ref_start, ref_end, d_workspace, stream)) return rc;
     const int stride = banded_stream_layout(len, k, nullptr, nullptr);
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, stride, kBandedRefill, 40, stream, &fault)) return rc;
     if (k <= 15)
         hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
-                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride);
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride, fault);
     else
         hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
-                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride);
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride, fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

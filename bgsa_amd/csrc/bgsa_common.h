@@ -31,7 +31,7 @@ void set_error_text(const char *text);
 int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                  int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                  void *d_workspace, hipStream_t stream, int semi_global = 0);
-const char *myers_kernel_name(int word_num);
+const char *myers_kernel_name(int word_num, int semi_global = 0);
 
 // Packed query stream (one per query, 8-byte windows): codes 0..4 = A C G T N row, 5 = END,
 // 6 = REFILL.  Window i < n_windows-1 holds characters 7i..7i+6 and a REFILL; the last window
@@ -97,14 +97,16 @@ int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, i
 // so the scalar work of the threaded-code dispatch is what its loop waits for; one token therefore
 // carries TWO consecutive rows whenever nothing has to happen between them:
 //   0..24   two rows, classes a then b: 5*a + b        25..29  one row of class c: 25 + c
-//   30 END  31 REFILL  32 EVENT, followed by an argument byte of bits: 1 = reset the error count
+//   30 END  31 REFILL  63 EVENT, followed by an argument byte of bits: 1 = reset the error count
 //   (row k), 2 = advance the match-string words (every 32 rows), 4 = test the limit on all lanes,
 //   8 = latch the reject mask (the reference's last checkpoint).
+// (EVENT is the last of the 64 slots the dispatch's 6-bit mask can reach, so its code may be longer than a
+// slot; 32..62 are fail slots: gen_rows_asm.py.)
 // A two-byte token never straddles a window: the window is closed early with a REFILL instead.
 // Writes the stream when dst != nullptr (row = mapped query characters); returns its length in bytes
 // including the spare window.  The same routine sizes the workspace on the host and fills it on the
 // device.
-constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill = kPairRefill, kBandedEvent = 32;
+constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill = kPairRefill, kBandedEvent = 63;
 // Upper bound of banded_stream_layout(len, k) over every k (sizes the workspace, which does not know k):
 // all rows as one-row tokens, every event two bytes plus one byte lost to an early window close.
 // Rows between two tests of the error limit (a wave stops as soon as all 64 lanes are past it).  The
@@ -224,29 +226,18 @@ struct BitpalSet {
 int bitpal_set_count();
 const BitpalSet *bitpal_set_at(int i);
 const BitpalSet *bitpal_find_set(int match, int mismatch, int gap);  // nullptr: not compiled in
-// The set that scores the ABI's score globals and the factor its results are multiplied by: the ints
-// divided by their common factor, as the reference's generator does (Main.java:213-267).  nullptr +
-// error text if that reduced set is not compiled in.
-const BitpalSet *bitpal_current_set(int *factor = nullptr);
+int bitpal_common_factor(int match, int mismatch, int gap);  // the generator's commonFactor (Main.java:213-238)
 
-// Scores with the set selected by the ABI's match_score / mismatch_score / gap_score.
-int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+// Scores with the kernels of compiled set `s` (capi.hip: make_plan picks it and the result factor).
+int launch_bitpal(const BitpalSet *s, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                   void *d_workspace, hipStream_t stream, int semi_global);
-const char *bitpal_kernel_name(int word_num);
+const char *bitpal_kernel_name(const BitpalSet *s, int word_num);
 
 // Widest subject (in words) the Myers kernels keep whole in registers; wider ones run as column blocks.
 int myers_max_plain_words();
 
-// long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits.
-inline bool beyond_registers(int algo, int word_num)
-{
-    if (algo == BGSA_ALGO_BITPAL) {
-        const BitpalSet *s = bitpal_current_set();
-        return s && word_num > s->max_plain;
-    }
-    return algo == BGSA_ALGO_MYERS && word_num > myers_max_plain_words();
-}
+// long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits (A/B only).
 // Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.
 // Persistent workgroups of the column-block kernels (each owns a carry buffer slice): 512 = two per CU.
 // BGSA_BLOCKED_WORKGROUPS overrides it for measurements.
@@ -304,6 +295,31 @@ int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len
                       int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream);
 int launch_map_queries(char *d_content, int64_t bytes, hipStream_t stream);
 int launch_scale_scores(int16_t *d_scores, int64_t count, int factor, hipStream_t stream);
+
+// ---- stream faults ------------------------------------------------------------------------------
+// Every generated row loop hands back what is left of its window budget (gen_rows_asm.py: S_LEFT): >= 0
+// after a well-formed stream, -1 if the budget ran out before an END token, -2 if a byte that is no
+// stream code was dispatched.  Either means the wave did not score its query — the kernel then raises a
+// bit in the device's sticky fault word instead of storing a wrong score silently.  The word lives in
+// device memory (one per device, allocated and zeroed at the first launch) and is read back by
+// bgsa_hip_stream_faults(); the host-buffer seams check it after every call.
+unsigned *device_fault_word();   // capi.hip; nullptr + error text if the allocation failed
+// One-shot fault injection for the tests of the above (bgsa_hip_debug_inject_stream_fault): the next
+// scoring launch of this process overwrites the first packed stream with REFILL codes (kind 1) or with a
+// byte that is no code (kind 2) between the packer and the scoring kernel.
+// Called by every launcher between its packer and its scoring kernel: fetches the fault word and applies
+// a pending injection.  refill_code = the REFILL token of this stream format; bad_code = a byte value
+// its dispatch sends to a fail slot, or -1 if the format has none (then kind 2 degrades to kind 1).
+int stream_guard(void *d_streams, int stride_bytes, int refill_code, int bad_code, hipStream_t stream,
+                 unsigned **fault_word);
+
+__device__ __forceinline__ void note_stream_fault(unsigned *fault_word, int left)
+{
+    if (left < 0) {  // wave-uniform: `left` comes back in an SGPR
+        if ((threadIdx.x & (kLanes - 1)) == 0)
+            atomicOr(fault_word, left == -1 ? static_cast<unsigned>(BGSA_HIP_FAULT_BUDGET) : static_cast<unsigned>(BGSA_HIP_FAULT_CODE));
+    }
+}
 
 // ---- device helpers ---------------------------------------------------------------------------
 

@@ -4,15 +4,11 @@
 // (generator/.../BitPAlGenerator.java, `-M -I -G`, README.md:26-82) and commits only 2/-3/-5
 // (original/BGSA_AVX2/align_core.c).  Here gen_bitpal_sets.py plays that role at build time: for
 // every score set in the Makefile's BITPAL_SETS it emits the row loops (rows_ir.py: bitpal_body) and a
-// translation unit that instantiates bitpal_kernels.inl for it; bitpal_sets.inc lists them.  The
-// kernels of the set matching the ABI's match_score / mismatch_score / gap_score globals run.
+// translation unit that instantiates bitpal_kernels.inl for it; bitpal_sets.inc lists them.  Which set
+// a call runs is decided in capi.hip (make_plan) from the caller's scores.
 #include <stdlib.h>
 
 #include "bgsa_common.h"
-
-extern "C" {
-extern int match_score, mismatch_score, gap_score;
-}
 
 namespace bgsa {
 
@@ -30,8 +26,8 @@ const BitpalSet *bitpal_find_set(int match, int mismatch, int gap)
     return nullptr;
 }
 
-namespace {
-int gcd3(int a, int b, int c)
+// commonFactor() of the generator (Main.java:213-238): the largest integer dividing all three
+int bitpal_common_factor(int match, int mismatch, int gap)
 {
     auto g = [](int x, int y) {
         x = x < 0 ? -x : x;
@@ -39,25 +35,8 @@ int gcd3(int a, int b, int c)
         while (y) { const int r = x % y; x = y; y = r; }
         return x;
     };
-    return g(g(a, b), c);
-}
-}  // namespace
-
-const BitpalSet *bitpal_current_set(int *factor)
-{
-    // commonFactor() of the generator (Main.java:213-238): the largest integer dividing all three
-    int f = gcd3(match_score, mismatch_score, gap_score);
-    if (f < 1) f = 1;
-    if (factor) *factor = f;
-    const BitpalSet *s = bitpal_find_set(match_score / f, mismatch_score / f, gap_score / f);
-    if (!s) {
-        char msg[224];
-        snprintf(msg, sizeof msg,
-                 "bitpal: no kernels compiled for match %d / mismatch %d / gap %d (reduced by their common factor %d; "
-                 "rebuild with BITPAL_SETS, see bgsa_hip_score_set())", match_score / f, mismatch_score / f, gap_score / f, f);
-        set_error_text(msg);
-    }
-    return s;
+    const int f = g(g(match, mismatch), gap);
+    return f < 1 ? 1 : f;
 }
 
 namespace {
@@ -72,31 +51,23 @@ bool bitpal_c_impl(const BitpalSet *s)
 }
 }  // namespace
 
-const char *bitpal_kernel_name(int word_num)
+const char *bitpal_kernel_name(const BitpalSet *s, int word_num)
 {
-    const BitpalSet *s = bitpal_current_set();
     if (!s) return "bitpal: score set not compiled";
     if (word_num > s->max_plain && bitpal_c_impl(s)) return "bitpal_long_kernel";
     return s->kernel_name(word_num);
 }
 
-int launch_bitpal(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+int launch_bitpal(const BitpalSet *s, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                   void *d_workspace, hipStream_t stream, int semi_global)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
-    int factor = 1;
-    const BitpalSet *s = bitpal_current_set(&factor);
-    if (!s) return BGSA_HIP_EUNSUPPORTED;
-    int rc;
     if (word_num > s->max_plain && bitpal_c_impl(s) && !semi_global)  // A/B: the state-in-memory C++ kernel
-        rc = launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
-                         ref_end, word_num, d_workspace, stream);
-    else
-        rc = s->launch(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
-                       d_workspace, stream, semi_global);
-    if (rc) return rc;
-    return launch_scale_scores(d_results, static_cast<int64_t>(ref_end - ref_start) * read_count, factor, stream);
+        return launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
+                           ref_end, word_num, d_workspace, stream);
+    return s->launch(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
+                     d_workspace, stream, semi_global);
 }
 
 }  // namespace bgsa

@@ -59,7 +59,7 @@ template <int NW, bool SEMI>
 __global__ __launch_bounds__(256) void bitpal_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes)
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
 {
     constexpr int semi = SEMI;
     const int lane = threadIdx.x & (kLanes - 1);
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
         for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);  // (:167-171)
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        bitpal_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        note_stream_fault(fault_word, bitpal_rows_asm<NW>(st, P, uniform_u64(s),
+                                                          __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
         int score;
         if (semi) {
             int run = kBitpalGap * ref_len;
@@ -104,7 +105,8 @@ template <int NW, bool SEMI>
 __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks, unsigned long long *task_counter)
+    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks, unsigned long long *task_counter,
+    unsigned *__restrict__ fault_word)
 {
     constexpr int semi = SEMI;
     constexpr int NC = kBitpalChains;
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
                     st[NS + NC + i] = 0u;
                 }
                 uint32_t voff = static_cast<uint32_t>(lane * 4);
-                bitpal_block_rows_asm<NW>(st, P, voff, carry_base, uniform_u64(s),
-                                          __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                note_stream_fault(fault_word, bitpal_block_rows_asm<NW>(st, P, voff, carry_base, uniform_u64(s),
+                                                                        __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
 #pragma unroll
                 for (int i = 0; i < NC; i++) {
                     const uint32_t word = tail_rows ? (st[NS + NC + i] << (32 - tail_rows)) : st[NS + NC + i];
@@ -193,12 +195,14 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     unsigned long long *counter = reinterpret_cast<unsigned long long *>(
         reinterpret_cast<unsigned char *>(carry) + blocked_carry_bytes(ref_len, kBitpalChains));
     BGSA_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, stride, kCodeRefill, -1, stream, &fault)) return rc;
     auto kernel = semi ? bitpal_blocked_kernel<NW, true> : bitpal_blocked_kernel<NW, false>;
     hipLaunchKernelGGL(kernel, dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
                        blocked_q_tile(nq, read_count / kLanes),
-                       stride, n_blocks, counter);
+                       stride, n_blocks, counter, fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -225,11 +229,13 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
         return BGSA_HIP_EUNSUPPORTED;
     }
     if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
     auto kernel = semi ? bitpal_asm_kernel<NW, true> : bitpal_asm_kernel<NW, false>;
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, static_cast<int>(stream_stride(ref_len)));
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

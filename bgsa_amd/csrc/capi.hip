@@ -4,14 +4,18 @@
 //   * the BGSA backend surface on HOST buffers (hip_handle_reads / align_hip /
 //     hip_cal_align_score + the globals every reference backend defines), so the library can be
 //     linked where original/BGSA_<ARCH>/{global.c,align_core.c,cal_<arch>.c} are linked;
-//   * the device-resident layer (bgsa_hip_*_dev) the pipeline driver and bench use.
+//   * the device-resident layer (bgsa_hip_*_dev / *_ex) the pipeline driver and bench use.
 // No CPU fallback anywhere: without a GPU every compute entry point fails loudly.
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
+#include <utility>
+#include <vector>
 
 #include "bgsa_common.h"
 
@@ -33,23 +37,6 @@ void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint3
 static int g_algo = BGSA_ALGO_MYERS;
 static int g_alignment = BGSA_ALIGN_GLOBAL;
 
-// Grow-only device workspace behind the host-buffer entry points.
-struct HostPathWorkspace {
-    void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr, *d_scratch = nullptr;
-    size_t cap_content = 0, cap_peq = 0, cap_results = 0, cap_scratch = 0;
-    int reserve(void **p, size_t *cap, size_t need)
-    {
-        if (need <= *cap) return BGSA_HIP_OK;
-        if (*p) BGSA_HIP_TRY(hipFree(*p));
-        *p = nullptr;
-        *cap = 0;
-        BGSA_HIP_TRY(hipMalloc(p, need));
-        *cap = need;
-        return BGSA_HIP_OK;
-    }
-};
-static HostPathWorkspace g_ws;
-
 [[noreturn]] static void die(const char *where)
 {
     // Reference convention: print and exit(1) (original/BGSA_CPU/file.c:13-16).
@@ -58,6 +45,178 @@ static HostPathWorkspace g_ws;
 }
 
 static size_t result_elem_size(int algo) { return algo == BGSA_ALGO_BANDED ? 1 : 2; }
+
+// ---- per-device sticky fault word (bgsa_common.h "stream faults") -----------------------------------
+static std::mutex g_fault_mu;
+static std::map<int, unsigned *> g_fault_words;
+static int g_inject_fault = 0;
+
+unsigned *device_fault_word()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        set_error_text("fault word: no current device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    auto it = g_fault_words.find(dev);
+    if (it != g_fault_words.end()) return it->second;
+    unsigned *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) {
+        set_error_text("fault word: device allocation failed");
+        return nullptr;
+    }
+    g_fault_words[dev] = p;
+    return p;
+}
+
+int take_injected_stream_fault()
+{
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    const int kind = g_inject_fault;
+    g_inject_fault = 0;
+    return kind;
+}
+
+__global__ void corrupt_stream_kernel(unsigned char *stream, int bytes, unsigned char value)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bytes) stream[i] = value;
+}
+
+int stream_guard(void *d_streams, int stride_bytes, int refill_code, int bad_code, hipStream_t stream,
+                 unsigned **fault_word)
+{
+    *fault_word = device_fault_word();
+    if (!*fault_word) return BGSA_HIP_EHIP;
+    const int kind = take_injected_stream_fault();
+    if (kind) {  // tests only: the first stream of this launch becomes all-REFILL, or all-<no code>
+        const int value = (kind == 2 && bad_code >= 0) ? bad_code : refill_code;
+        hipLaunchKernelGGL(corrupt_stream_kernel, dim3((stride_bytes + 63) / 64), dim3(64), 0, stream,
+                           static_cast<unsigned char *>(d_streams), stride_bytes, static_cast<unsigned char>(value));
+        BGSA_HIP_TRY(hipGetLastError());
+    }
+    return BGSA_HIP_OK;
+}
+
+// ---- library-owned scratch for callers that pass no workspace ---------------------------------------
+// One grow-only buffer per (device, stream): launches on one stream are ordered, so the pack -> score
+// sequence of consecutive calls cannot overlap on it; calls that use it hold `g_scratch_mu` for the whole
+// launch sequence (two host threads sharing a stream would otherwise interleave their packers), and a
+// buffer is only freed after its stream has drained.
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+static std::mutex g_scratch_mu;
+static std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+
+static int scratch_reserve(hipStream_t stream, size_t need, void **out)  // g_scratch_mu held
+{
+    int dev = 0;
+    BGSA_HIP_TRY(hipGetDevice(&dev));
+    Scratch &e = g_scratch[{dev, stream}];
+    if (need > e.cap) {
+        if (e.p) {
+            BGSA_HIP_TRY(hipStreamSynchronize(stream));  // an earlier launch may still be reading it
+            BGSA_HIP_TRY(hipFree(e.p));
+        }
+        e.p = nullptr;
+        e.cap = 0;
+        BGSA_HIP_TRY(hipMalloc(&e.p, need));
+        e.cap = need;
+    }
+    *out = e.p;
+    return BGSA_HIP_OK;
+}
+
+// ---- what a set of scoring parameters runs as ---------------------------------------------------------
+struct Plan {
+    int kernel;               // BGSA_ALGO_* of the kernel family that runs
+    const BitpalSet *set;     // BitPAl kernels of this compiled set (kernel == BGSA_ALGO_BITPAL)
+    int factor;               // results are multiplied by this
+    int semi;
+};
+
+// The generator's score handling (Main.java:213-271) plus two normalisations of its domain:
+//   * a mismatch scoring below two gaps is never taken (insert + delete costs 2*gap), so any
+//     mismatch < 2*gap is the mismatch = 2*gap instance;
+//   * scores with a common factor f run as the reduced set and the result is multiplied by f;
+//   * the reduced set 0/-1/-1 in global mode is minus the edit distance: it runs on the Myers body
+//     (10 VALU per word against 22 for the BitPAl body of that set) — the reference's `isEdit`
+//     specialisation (Main.java:270-271) taken to its conclusion.
+static int make_plan(const bgsa_hip_params_t &p, Plan *plan)
+{
+    plan->set = nullptr;
+    plan->factor = 1;
+    plan->semi = p.alignment == BGSA_ALIGN_SEMIGLOBAL;
+    plan->kernel = p.algo;
+    switch (p.algo) {
+    case BGSA_ALGO_MYERS:
+        // weights (0, 1, 1) — the generator's `-m 1` — report +distance; anything else (0/-1/-1, or the ints
+        // of a BitPAl selection still in place while `algo` asks for Myers) the reference's -distance
+        plan->factor = (p.match == 0 && p.mismatch == 1 && p.gap == 1) ? -1 : 1;
+        return BGSA_HIP_OK;
+    case BGSA_ALGO_BANDED:
+        if (plan->semi) {
+            set_error_text("cal_align_score: semi-global alignment is not defined for the banded filter");
+            return BGSA_HIP_EUNSUPPORTED;
+        }
+        return BGSA_HIP_OK;
+    case BGSA_ALGO_BITPAL: {
+        int m = p.match, x = p.mismatch, g = p.gap;
+        if (!(g < 0 && m > x)) {
+            set_error_text("bitpal: scores need match > mismatch and gap < 0");
+            return BGSA_HIP_EUNSUPPORTED;
+        }
+        if (x < 2 * g) x = 2 * g;
+        const int f = bitpal_common_factor(m, x, g);
+        m /= f; x /= f; g /= f;
+        plan->factor = f;
+        if (m == 0 && x == -1 && g == -1 && !plan->semi) {
+            plan->kernel = BGSA_ALGO_MYERS;
+            return BGSA_HIP_OK;
+        }
+        plan->set = bitpal_find_set(m, x, g);
+        if (!plan->set) {
+            char msg[256];
+            snprintf(msg, sizeof msg,
+                     "bitpal: no kernels compiled for match %d / mismatch %d / gap %d (= %d/%d/%d reduced by the common "
+                     "factor %d; rebuild with BITPAL_SETS, see bgsa_hip_score_set())", m, x, g, p.match, p.mismatch, p.gap, f);
+            set_error_text(msg);
+            return BGSA_HIP_EUNSUPPORTED;
+        }
+        return BGSA_HIP_OK;
+    }
+    default:
+        set_error_text("unknown algorithm");
+        return BGSA_HIP_EINVAL;
+    }
+}
+
+static bool plan_beyond_registers(const Plan &plan, int word_num)
+{
+    if (plan.kernel == BGSA_ALGO_BITPAL) return word_num > plan.set->max_plain;
+    return plan.kernel == BGSA_ALGO_MYERS && word_num > myers_max_plain_words();
+}
+
+static size_t plan_workspace_bytes(const Plan &plan, int ref_len, int read_len, int n_queries)
+{
+    if (ref_len <= 0 || n_queries <= 0) return 0;
+    const int algo = plan.kernel;
+    if (read_len > 0 && plan_beyond_registers(plan, (read_len + 31) / 32)) {  // column blocks: streams + carry buffers
+        const int chains = algo == BGSA_ALGO_BITPAL ? plan.set->chains : 3;
+        const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
+                               blocked_carry_bytes(ref_len, chains) + 256;   // + the task counter
+        // the A/B state-in-memory kernels (BGSA_MYERS_IMPL=c / BGSA_BITPAL_IMPL=c) keep the DP state here
+        const char *ab = getenv(algo == BGSA_ALGO_BITPAL ? "BGSA_BITPAL_IMPL" : "BGSA_MYERS_IMPL");
+        const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
+        return blocked > in_memory ? blocked : in_memory;
+    }
+    if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k: sized for the worst k
+        return banded_stream_bound(ref_len) * n_queries;
+    return stream_stride(ref_len) * static_cast<size_t>(n_queries);
+}
 
 }  // namespace bgsa
 
@@ -85,13 +244,45 @@ void init_mapping_table(void)
     mapping_table[(int)'N'] = 4;
 }
 
+// malloc_mem / free_mem (reference global.c:17-23: _mm_malloc(size, 64)).  Every large buffer of the
+// reference's pipeline comes from here (cal_cpu.c:206-267: row buffers, Peq A/B, result A/B), so handing
+// out page-locked memory makes all of the host seams' copies full-rate DMA without the host code knowing.
+// Small blocks, and everything when no GPU is visible, come from the C heap.
+static std::mutex g_pinned_mu;
+static std::set<void *> g_pinned;
+static const size_t kPinThreshold = 1u << 20;
+
 void *malloc_mem(uint64_t size)
 {
+    if (size >= kPinThreshold) {
+        int n = 0;
+        void *p = nullptr;
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0 &&
+            hipHostMalloc(&p, size, hipHostMallocPortable) == hipSuccess && p) {
+            std::lock_guard<std::mutex> lock(g_pinned_mu);
+            g_pinned.insert(p);
+            return p;
+        }
+        (void)hipGetLastError();
+    }
     void *p = nullptr;
     if (posix_memalign(&p, 64, size ? size : 64) != 0) return nullptr;
     return p;
 }
-void free_mem(void *mem) { free(mem); }
+void free_mem(void *mem)
+{
+    if (!mem) return;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mu);
+        auto it = g_pinned.find(mem);
+        if (it != g_pinned.end()) {
+            g_pinned.erase(it);
+            (void)hipHostFree(mem);
+            return;
+        }
+    }
+    free(mem);
+}
 
 int bgsa_hip_select_algorithm(int algo)
 {
@@ -126,6 +317,18 @@ int bgsa_hip_select_alignment(int mode)
 }
 int bgsa_hip_current_alignment(void) { return g_alignment; }
 
+int bgsa_hip_current_params(bgsa_hip_params_t *out)
+{
+    if (!out) return BGSA_HIP_EINVAL;
+    out->algo = g_algo;
+    out->alignment = g_alignment;
+    out->match = match_score;
+    out->mismatch = mismatch_score;
+    out->gap = gap_score;
+    out->k = threshold;
+    return BGSA_HIP_OK;
+}
+
 int bgsa_hip_select_scores(int match, int mismatch, int gap)
 {
     if (match == 0 && mismatch == 1 && gap == 1) {  // the generator's `-m 1`: Myers, result = +distance
@@ -133,15 +336,9 @@ int bgsa_hip_select_scores(int match, int mismatch, int gap)
         mismatch_score = 1; gap_score = 1;
         return BGSA_HIP_OK;
     }
-    const int old_m = match_score, old_x = mismatch_score, old_g = gap_score;
-    match_score = match; mismatch_score = mismatch; gap_score = gap;
-    const bool ok = match > mismatch && mismatch >= 2 * gap && gap < 0 && bitpal_current_set() != nullptr;
-    match_score = old_m; mismatch_score = old_x; gap_score = old_g;
-    if (!ok) {
-        if (!(match > mismatch && mismatch >= 2 * gap && gap < 0))
-            set_error_text("select_scores: BitPAl needs match > mismatch >= 2*gap and gap < 0");
-        return BGSA_HIP_EUNSUPPORTED;
-    }
+    bgsa_hip_params_t p = {BGSA_ALGO_BITPAL, BGSA_ALIGN_GLOBAL, match, mismatch, gap, 0};
+    Plan plan;
+    if (int rc = make_plan(p, &plan)) return rc == BGSA_HIP_EINVAL ? BGSA_HIP_EUNSUPPORTED : rc;
     if (int rc = bgsa_hip_select_algorithm(BGSA_ALGO_BITPAL)) return rc;
     match_score = match; mismatch_score = mismatch; gap_score = gap;
     return BGSA_HIP_OK;
@@ -182,18 +379,6 @@ size_t bgsa_hip_group_words(int algo, int word_num, int k)
     return static_cast<size_t>(BGSA_CHAR_NUM) * word_num * HIP_V_NUM;
 }
 
-int bgsa_hip_release_workspace(void)
-{
-    void **slots[] = {&g_ws.d_content, &g_ws.d_peq, &g_ws.d_results, &g_ws.d_scratch};
-    size_t *caps[] = {&g_ws.cap_content, &g_ws.cap_peq, &g_ws.cap_results, &g_ws.cap_scratch};
-    for (int i = 0; i < 4; i++) {
-        if (*slots[i]) BGSA_HIP_TRY(hipFree(*slots[i]));
-        *slots[i] = nullptr;
-        *caps[i] = 0;
-    }
-    return BGSA_HIP_OK;
-}
-
 // ---- device-resident layer ---------------------------------------------------------------------
 
 const char *bgsa_hip_last_error(void) { return g_last_error.c_str(); }
@@ -223,7 +408,7 @@ int bgsa_hip_free(void *dptr)
 int bgsa_hip_malloc_host(void **hptr, size_t bytes)
 {
     if (!hptr) return BGSA_HIP_EINVAL;
-    BGSA_HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    BGSA_HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocPortable));
     return BGSA_HIP_OK;
 }
 int bgsa_hip_free_host(void *hptr)
@@ -256,12 +441,90 @@ int bgsa_hip_stream_create(void **stream)
 }
 int bgsa_hip_stream_destroy(void *stream)
 {
+    {   // its library-owned scratch goes with it
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            auto it = g_scratch.find({dev, static_cast<hipStream_t>(stream)});
+            if (it != g_scratch.end()) {
+                (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+                if (it->second.p) (void)hipFree(it->second.p);
+                g_scratch.erase(it);
+            }
+        }
+    }
     BGSA_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
     return BGSA_HIP_OK;
 }
 int bgsa_hip_stream_synchronize(void *stream)
 {
     BGSA_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_event_create(void **event)
+{
+    if (!event) return BGSA_HIP_EINVAL;
+    hipEvent_t e;
+    BGSA_HIP_TRY(hipEventCreate(&e));
+    *event = e;
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_event_destroy(void *event)
+{
+    BGSA_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_event_record(void *event, void *stream)
+{
+    BGSA_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_event_synchronize(void *event)
+{
+    BGSA_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!ms) return BGSA_HIP_EINVAL;
+    BGSA_HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return BGSA_HIP_OK;
+}
+int bgsa_hip_stream_wait_event(void *stream, void *event)
+{
+    BGSA_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_stream_faults(int clear)
+{
+    int dev = 0;
+    BGSA_HIP_TRY(hipGetDevice(&dev));
+    unsigned *word = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_fault_mu);
+        auto it = g_fault_words.find(dev);
+        if (it == g_fault_words.end()) return 0;  // nothing was ever launched on this device
+        word = it->second;
+    }
+    unsigned value = 0;
+    BGSA_HIP_TRY(hipMemcpy(&value, word, sizeof value, hipMemcpyDeviceToHost));
+    if (value && clear) BGSA_HIP_TRY(hipMemset(word, 0, sizeof value));
+    if (value) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "stream fault on device %d: flags 0x%x (%s%s) — at least one query was not scored", dev, value,
+                 (value & BGSA_HIP_FAULT_BUDGET) ? "window budget exhausted before END " : "",
+                 (value & BGSA_HIP_FAULT_CODE) ? "byte that is no stream code dispatched" : "");
+        set_error_text(msg);
+    }
+    return static_cast<int>(value);
+}
+
+int bgsa_hip_debug_inject_stream_fault(int kind)
+{
+    if (kind < 0 || kind > 2) return BGSA_HIP_EINVAL;
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    g_inject_fault = kind;
     return BGSA_HIP_OK;
 }
 
@@ -272,6 +535,10 @@ int bgsa_hip_handle_reads_dev(int algo, const char *d_rows, int64_t avail_bytes,
     if (!d_rows || !d_peq || len <= 0 || read_count < 0 || word_num <= 0 ||
         (read_count % HIP_V_NUM) != 0) {
         set_error_text("handle_reads_dev: bad argument (read_count must be a multiple of 64)");
+        return BGSA_HIP_EINVAL;
+    }
+    if (word_num != bgsa_hip_word_num(algo, len, len, k)) {
+        set_error_text("handle_reads_dev: word_num is not bgsa_hip_word_num() for this algorithm and length");
         return BGSA_HIP_EINVAL;
     }
     return launch_preprocess(algo, d_rows, avail_bytes, len, read_count, word_num, k, d_peq,
@@ -287,28 +554,30 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream)
     return launch_map_queries(d_content, bytes, static_cast<hipStream_t>(stream));
 }
 
-size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries)
+size_t bgsa_hip_workspace_bytes_ex(const bgsa_hip_params_t *params, int ref_len, int read_len, int n_queries)
 {
-    if (ref_len <= 0 || n_queries <= 0) return 0;
-    if (read_len > 0 && beyond_registers(algo, (read_len + 31) / 32)) {  // column blocks: streams + carry buffers
-        const int chains = algo == BGSA_ALGO_BITPAL ? bitpal_current_set()->chains : 3;  // non-null: beyond_registers() saw it
-        const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
-                               blocked_carry_bytes(ref_len, chains) + 256;   // + the task counter
-        // the A/B state-in-memory kernels (BGSA_MYERS_IMPL=c / BGSA_BITPAL_IMPL=c) keep the DP state here
-        const char *ab = getenv(algo == BGSA_ALGO_BITPAL ? "BGSA_BITPAL_IMPL" : "BGSA_MYERS_IMPL");
-        const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
-        return blocked > in_memory ? blocked : in_memory;
-    }
-    if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k, which this query does not know
-        return banded_stream_bound(ref_len) * n_queries;
-    return stream_stride(ref_len) * static_cast<size_t>(n_queries);
+    Plan plan;
+    if (!params || make_plan(*params, &plan)) return 0;
+    return plan_workspace_bytes(plan, ref_len, read_len, n_queries);
 }
 
-int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read_t *d_peq,
-                                 void *d_results, int ref_len, int read_len, int64_t read_count,
-                                 int ref_start, int ref_end, int word_num, int k,
-                                 void *d_workspace, size_t workspace_bytes, void *stream)
+size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries)
 {
+    bgsa_hip_params_t p;
+    bgsa_hip_current_params(&p);
+    p.algo = algo;
+    return bgsa_hip_workspace_bytes_ex(&p, ref_len, read_len, n_queries);
+}
+
+int bgsa_hip_cal_align_score_ex(const bgsa_hip_params_t *params, const char *d_content, const hip_read_t *d_peq,
+                                void *d_results, int ref_len, int read_len, int64_t read_count,
+                                int ref_start, int ref_end, int word_num,
+                                void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!params) {
+        set_error_text("cal_align_score: params is NULL");
+        return BGSA_HIP_EINVAL;
+    }
     if (ref_start >= 0 && ref_end >= ref_start && read_count >= 0 && (ref_end == ref_start || read_count == 0))
         return BGSA_HIP_OK;  // an empty query window or an empty bucket: nothing to score
     if (!d_content || !d_peq || !d_results || ref_len <= 0 || read_len <= 0 || read_count < 0 ||
@@ -316,53 +585,60 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
         set_error_text("cal_align_score_dev: bad argument (read_count must be a multiple of 64)");
         return BGSA_HIP_EINVAL;
     }
-    if (g_alignment == BGSA_ALIGN_SEMIGLOBAL && algo == BGSA_ALGO_BANDED) {
-        set_error_text("cal_align_score_dev: semi-global alignment is not defined for the banded filter");
-        return BGSA_HIP_EUNSUPPORTED;
+    Plan plan;
+    if (int rc = make_plan(*params, &plan)) return rc;
+    // the kernels index the Peq / Mext blocks with the caller's word_num: it must be the layout's
+    if (word_num != bgsa_hip_word_num(params->algo, ref_len, read_len, params->k)) {
+        set_error_text(params->algo == BGSA_ALGO_BANDED
+                           ? "cal_align_score_dev: word_num is not bgsa_hip_word_num(BGSA_ALGO_BANDED, ...) — the Mext layout "
+                             "has ceil(len/32)+3 words, not the reference's banded formula (cal_cpu.c:253-254)"
+                           : "cal_align_score_dev: word_num does not match read_len");
+        return BGSA_HIP_EINVAL;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t need = bgsa_hip_workspace_bytes(algo, ref_len, read_len, ref_end - ref_start);
+    const size_t need = plan_workspace_bytes(plan, ref_len, read_len, ref_end - ref_start);
+    std::unique_lock<std::mutex> own_scratch(g_scratch_mu, std::defer_lock);
     if (d_workspace) {
         if (workspace_bytes < need) {
             set_error_text("cal_align_score_dev: workspace smaller than bgsa_hip_workspace_bytes()");
             return BGSA_HIP_EINVAL;
         }
     } else {
-        if (g_ws.reserve(&g_ws.d_scratch, &g_ws.cap_scratch, need)) return BGSA_HIP_EHIP;
-        d_workspace = g_ws.d_scratch;
+        own_scratch.lock();
+        if (int rc = scratch_reserve(s, need, &d_workspace)) return rc;
     }
-    switch (algo) {
+    const int64_t n_scores = static_cast<int64_t>(ref_end - ref_start) * read_count;
+    switch (plan.kernel) {
     case BGSA_ALGO_MYERS:
-        if (word_num != (read_len + 31) / 32) {
-            set_error_text("cal_align_score_dev: word_num does not match read_len for Myers");
-            return BGSA_HIP_EINVAL;
-        }
-    {
-        // weights (0, 1, 1) — the generator's `-m 1` — report +distance; anything else (0/-1/-1, or the ints
-        // of a BitPAl selection still in place while `algo` asks for Myers) the reference's -distance
-        const bool positive = match_score == 0 && mismatch_score == 1 && gap_score == 1;
         if (int rc = launch_myers(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len, read_len,
-                                  read_count, ref_start, ref_end, word_num, d_workspace, s,
-                                  g_alignment == BGSA_ALIGN_SEMIGLOBAL))
+                                  read_count, ref_start, ref_end, word_num, d_workspace, s, plan.semi))
             return rc;
-        return launch_scale_scores(static_cast<int16_t *>(d_results), static_cast<int64_t>(ref_end - ref_start) * read_count,
-                                   positive ? -1 : 1, s);
-    }
+        return launch_scale_scores(static_cast<int16_t *>(d_results), n_scores, plan.factor, s);
     case BGSA_ALGO_BANDED:
         return launch_banded(d_content, d_peq, static_cast<int8_t *>(d_results), ref_len, read_len,
-                             read_count, ref_start, ref_end, word_num, k, d_workspace, s);
+                             read_count, ref_start, ref_end, word_num, params->k, d_workspace, s);
     case BGSA_ALGO_BITPAL:
-        if (word_num != (read_len + 31) / 32) {
-            set_error_text("cal_align_score_dev: word_num does not match read_len for BitPAl");
-            return BGSA_HIP_EINVAL;
-        }
-        return launch_bitpal(d_content, d_peq, static_cast<int16_t *>(d_results), ref_len,
-                             read_len, read_count, ref_start, ref_end, word_num, d_workspace, s,
-                             g_alignment == BGSA_ALIGN_SEMIGLOBAL);
+        if (int rc = launch_bitpal(plan.set, d_content, d_peq, static_cast<int16_t *>(d_results), ref_len,
+                                   read_len, read_count, ref_start, ref_end, word_num, d_workspace, s, plan.semi))
+            return rc;
+        return launch_scale_scores(static_cast<int16_t *>(d_results), n_scores, plan.factor, s);
     default:
         set_error_text("cal_align_score_dev: unknown algorithm");
         return BGSA_HIP_EINVAL;
     }
+}
+
+int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read_t *d_peq,
+                                 void *d_results, int ref_len, int read_len, int64_t read_count,
+                                 int ref_start, int ref_end, int word_num, int k,
+                                 void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    bgsa_hip_params_t p;  // the process-global selection, read once, here
+    bgsa_hip_current_params(&p);
+    p.algo = algo;
+    p.k = k;
+    return bgsa_hip_cal_align_score_ex(&p, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
+                                       ref_end, word_num, d_workspace, workspace_bytes, stream);
 }
 
 int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, unsigned char *dst, int cap)
@@ -398,15 +674,202 @@ int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, 
 
 const char *bgsa_hip_kernel_name(int algo, int word_num)
 {
-    switch (algo) {
-    case BGSA_ALGO_MYERS: return myers_kernel_name(word_num);
+    bgsa_hip_params_t p;
+    bgsa_hip_current_params(&p);
+    p.algo = algo;
+    Plan plan;
+    if (make_plan(p, &plan)) return algo == BGSA_ALGO_BITPAL ? "bitpal: score set not compiled" : "";
+    switch (plan.kernel) {
+    case BGSA_ALGO_MYERS: return myers_kernel_name(word_num, plan.semi);
     case BGSA_ALGO_BANDED: return banded_kernel_name(word_num);
-    case BGSA_ALGO_BITPAL: return bitpal_kernel_name(word_num);
+    case BGSA_ALGO_BITPAL: return bitpal_kernel_name(plan.set, word_num);
     default: return "";
     }
 }
 
 // ---- BGSA backend surface on host buffers --------------------------------------------------------
+//
+// The seams take host buffers and return when the results are in host memory, like the reference's.
+// Behind them (one instance per process, guarded by `g_seam`):
+//   * device mirrors of the query buffer, the Peq bucket and the result tile, grow-only;
+//   * RESIDENT BUCKETS: hip_handle_reads remembers the host range it filled; the first scoring call on
+//     that range uploads it and later calls reuse the device copy until hip_handle_reads (or
+//     bgsa_hip_bucket_release) touches the range again — what the KNC backend does with `nocopy ... RETAIN`
+//     (BGSA_KNC/cal_mic.c:348-356).  The reference's loop scores 100 queries per call against the same
+//     bucket (cal_cpu.c:363-401), so the 100 MB of Peq cross PCIe once per bucket instead of once per
+//     call.  A host that builds Peq words itself registers them with bgsa_hip_bucket_resident();
+//     bgsa_hip_set_auto_resident(0) restores upload-on-every-call;
+//   * the query buffer is re-uploaded only when its bytes changed (memcmp against a host copy: 1.5 MB);
+//   * copies are asynchronous on a private stream; buffers from malloc_mem() are page-locked.
+
+struct ResidentRange {
+    const unsigned char *host = nullptr;   // host address of the Peq words
+    size_t bytes = 0;                      // host bytes
+    int w_host = 0, w_dev = 0;             // 32-bit words per class and lane: host layout, device layout
+    void *dev = nullptr;                   // device mirror (nullptr: not uploaded yet)
+    int device = -1;
+    bool uploaded = false;
+};
+
+// 32-bit words per (class, lane) of a HOST Peq buffer whose caller passed `word_num`, or -1.  Myers and
+// BitPAl: the library's own layout only.  Banded: the library's Mext layout (ceil(len/32)+3 words of
+// uint32), or the size the reference's banded host computes — word_num = (len - h + 63)/64 + 1 words of
+// its 64-bit cpu_read_t (banded/BGSA_CPU/cal_cpu.c:253-254, config.h:26) = twice as many 32-bit words.
+// That buffer always holds the len + k + 1 bits of the offset match string (k <= 31), but not the zero
+// words behind it that the kernels' 64-bit windows and prefetch rely on, so the seams re-pitch it to the
+// device layout on upload.
+static int host_words32(int algo, int len, int k, int word_num)
+{
+    const int own = bgsa_hip_word_num(algo, len, len, k);
+    if (word_num == own) return own;
+    if (algo == BGSA_ALGO_BANDED && word_num == (len - k + 63) / 64 + 1) return 2 * word_num;
+    return -1;
+}
+
+// Host Peq blocks [group][class][w_host][lane] -> device blocks [group][class][w_dev][lane].
+static int upload_peq(void *dev, const void *host, size_t groups, int w_host, int w_dev, hipStream_t s)
+{
+    const size_t rows = groups * BGSA_CHAR_NUM;
+    if (w_host == w_dev) {
+        BGSA_HIP_TRY(hipMemcpyAsync(dev, host, rows * w_dev * 256, hipMemcpyHostToDevice, s));
+        return BGSA_HIP_OK;
+    }
+    BGSA_HIP_TRY(hipMemsetAsync(dev, 0, rows * w_dev * 256, s));
+    const int w = w_host < w_dev ? w_host : w_dev;
+    BGSA_HIP_TRY(hipMemcpy2DAsync(dev, static_cast<size_t>(w_dev) * 256, host, static_cast<size_t>(w_host) * 256,
+                                  static_cast<size_t>(w) * 256, rows, hipMemcpyHostToDevice, s));
+    return BGSA_HIP_OK;
+}
+
+struct HostSeam {
+    hipStream_t stream = nullptr;
+    int device = -1;
+    void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr;
+    size_t cap_content = 0, cap_peq = 0, cap_results = 0;
+    std::vector<unsigned char> content_copy;   // what d_content holds
+    std::vector<ResidentRange> ranges;
+    bool auto_resident = true;
+    uint64_t peq_uploads = 0, peq_upload_bytes = 0, calls = 0;
+    int reserve(void **p, size_t *cap, size_t need)
+    {
+        if (need <= *cap) return BGSA_HIP_OK;
+        if (*p) BGSA_HIP_TRY(hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+        BGSA_HIP_TRY(hipMalloc(p, need));
+        *cap = need;
+        return BGSA_HIP_OK;
+    }
+};
+static std::mutex g_seam;
+static HostSeam g_host;
+
+static void drop_overlapping(const unsigned char *lo, size_t bytes)  // g_seam held
+{
+    for (size_t i = 0; i < g_host.ranges.size();) {
+        ResidentRange &r = g_host.ranges[i];
+        if (lo < r.host + r.bytes && r.host < lo + bytes) {
+            if (r.dev) (void)hipFree(r.dev);
+            g_host.ranges.erase(g_host.ranges.begin() + i);
+        } else {
+            i++;
+        }
+    }
+}
+
+static int seam_stream()  // g_seam held
+{
+    int dev = 0;
+    BGSA_HIP_TRY(hipGetDevice(&dev));
+    if (g_host.stream && g_host.device == dev) return BGSA_HIP_OK;
+    if (g_host.stream) {   // the caller moved to another device: start over there
+        (void)hipStreamSynchronize(g_host.stream);
+        (void)hipStreamDestroy(g_host.stream);
+        g_host.stream = nullptr;
+        for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        g_host.cap_content = g_host.cap_peq = g_host.cap_results = 0;
+        g_host.content_copy.clear();
+        for (ResidentRange &r : g_host.ranges) {
+            if (r.dev) (void)hipFree(r.dev);
+            r.dev = nullptr;
+            r.uploaded = false;
+        }
+    }
+    BGSA_HIP_TRY(hipStreamCreateWithFlags(&g_host.stream, hipStreamNonBlocking));
+    g_host.device = dev;
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_set_auto_resident(int on)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    g_host.auto_resident = on != 0;
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_bucket_resident(const hip_read_t *host_peq, size_t bytes, int word_num)
+{
+    if (!host_peq || bytes == 0 || word_num <= 0 || bytes % (static_cast<size_t>(BGSA_CHAR_NUM) * word_num * 256) != 0) {
+        set_error_text("bucket_resident: bad argument (bytes must be whole groups of 5 x word_num x 64 words)");
+        return BGSA_HIP_EINVAL;
+    }
+    std::lock_guard<std::mutex> turn(g_seam);
+    const unsigned char *lo = reinterpret_cast<const unsigned char *>(host_peq);
+    drop_overlapping(lo, bytes);
+    ResidentRange r;
+    r.host = lo;
+    r.bytes = bytes;
+    r.w_host = r.w_dev = word_num;   // the library's own layout
+    g_host.ranges.push_back(r);
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_bucket_release(const hip_read_t *host_peq)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    if (g_host.stream) (void)hipStreamSynchronize(g_host.stream);
+    if (!host_peq) {
+        drop_overlapping(nullptr, ~static_cast<size_t>(0));
+        return BGSA_HIP_OK;
+    }
+    drop_overlapping(reinterpret_cast<const unsigned char *>(host_peq), 1);
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_upload_bytes)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    if (calls) *calls = g_host.calls;
+    if (peq_uploads) *peq_uploads = g_host.peq_uploads;
+    if (peq_upload_bytes) *peq_upload_bytes = g_host.peq_upload_bytes;
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_release_workspace(void)
+{
+    {
+        std::lock_guard<std::mutex> turn(g_seam);
+        if (g_host.stream) (void)hipStreamSynchronize(g_host.stream);
+        for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results}) {
+            if (*p) BGSA_HIP_TRY(hipFree(*p));
+            *p = nullptr;
+        }
+        g_host.cap_content = g_host.cap_peq = g_host.cap_results = 0;
+        g_host.content_copy.clear();
+        drop_overlapping(nullptr, ~static_cast<size_t>(0));
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto &kv : g_scratch) {
+        if (!kv.second.p) continue;
+        (void)hipStreamSynchronize(kv.first.second);
+        BGSA_HIP_TRY(hipFree(kv.second.p));
+    }
+    g_scratch.clear();
+    return BGSA_HIP_OK;
+}
 
 void hip_handle_reads(seq_t *read_seq, hip_read_t *result_reads, int word_num, int64_t read_start,
                       int64_t read_count)
@@ -416,10 +879,31 @@ void hip_handle_reads(seq_t *read_seq, hip_read_t *result_reads, int word_num, i
         die("hip_handle_reads");
     }
     const int len = read_seq->len;
+    const int algo = g_algo, k = threshold;
+    const int w_host = host_words32(algo, len, k, word_num);
+    if (w_host < 0) {
+        set_error_text("hip_handle_reads: word_num matches neither bgsa_hip_word_num() nor, for the banded filter, "
+                       "the reference's (len - h + 63)/64 + 1 (banded/BGSA_CPU/cal_cpu.c:253-254)");
+        die("hip_handle_reads");
+    }
     const int64_t off = read_start * static_cast<int64_t>(len + 1);
     int threads = cpu_threads > 0 ? cpu_threads : static_cast<int>(std::thread::hardware_concurrency());
-    host_handle_reads(g_algo, read_seq->content + off, read_seq->size - off, len, result_reads,
-                      word_num, read_count, threshold, threads);
+    const size_t bytes = static_cast<size_t>(BGSA_CHAR_NUM) * w_host * 256 * (static_cast<size_t>(read_count) / HIP_V_NUM);
+    {   // the range is about to change: forget any device copy of it
+        std::lock_guard<std::mutex> turn(g_seam);
+        drop_overlapping(reinterpret_cast<const unsigned char *>(result_reads), bytes ? bytes : 1);
+    }
+    host_handle_reads(algo, read_seq->content + off, read_seq->size - off, len, result_reads,
+                      w_host, read_count, k, threads);
+    std::lock_guard<std::mutex> turn(g_seam);
+    if (g_host.auto_resident && bytes) {
+        ResidentRange r;
+        r.host = reinterpret_cast<const unsigned char *>(result_reads);
+        r.bytes = bytes;
+        r.w_host = w_host;
+        r.w_dev = bgsa_hip_word_num(algo, len, len, k);
+        g_host.ranges.push_back(r);
+    }
 }
 
 void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_t *align_results,
@@ -429,33 +913,82 @@ void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_
     (void)chunk_read_num;  // CPU cache-blocking knob (cal_cpu.c:266); the GPU grid tiles itself
     (void)dvdh_bit_mem;    // per-thread scratch of the CPU kernels; state lives in VGPRs here
     if (ref_end <= ref_start || read_count <= 0) return;
-    // The reference calls align_<arch> from its OpenMP workers (cal_cpu.c:63-84): the staging buffers
+    // The reference calls align_<arch> from its OpenMP workers (cal_cpu.c:63-84): the device mirrors
     // below are shared, so concurrent callers take turns.
-    static std::mutex seam;
-    std::lock_guard<std::mutex> turn(seam);
+    std::lock_guard<std::mutex> turn(g_seam);
+    bgsa_hip_params_t params;   // the process-global selection, read once per call, under the lock
+    bgsa_hip_current_params(&params);
+    g_host.calls++;
+    if (seam_stream()) die("hip_cal_align_score");
+    hipStream_t s = g_host.stream;
     const size_t content_bytes = static_cast<size_t>(ref_count) * (ref_len + 1);
-    const size_t peq_bytes = bgsa_hip_group_words(g_algo, word_num, threshold) * sizeof(hip_read_t) *
-                             (static_cast<size_t>(read_count) / HIP_V_NUM);
-    const size_t res_bytes = static_cast<size_t>(ref_end - ref_start) * read_count * result_elem_size(g_algo);
-    if (g_ws.reserve(&g_ws.d_content, &g_ws.cap_content, content_bytes + 8) ||
-        g_ws.reserve(&g_ws.d_peq, &g_ws.cap_peq, peq_bytes) ||
-        g_ws.reserve(&g_ws.d_results, &g_ws.cap_results, res_bytes))
-        die("hip_cal_align_score");
-    if (hipMemcpy(g_ws.d_content, content, content_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(g_ws.d_peq, preprocess_reads, peq_bytes, hipMemcpyHostToDevice) != hipSuccess) {
-        set_error_text("hipMemcpy H2D failed");
+    const int w_host = host_words32(params.algo, read_len, params.k, word_num);
+    if (w_host < 0) {
+        set_error_text("hip_cal_align_score: word_num matches neither bgsa_hip_word_num() nor, for the banded filter, "
+                       "the reference's (len - h + 63)/64 + 1 (banded/BGSA_CPU/cal_cpu.c:253-254)");
         die("hip_cal_align_score");
     }
-    if (bgsa_hip_cal_align_score_dev(g_algo, static_cast<const char *>(g_ws.d_content),
-                                     static_cast<const hip_read_t *>(g_ws.d_peq), g_ws.d_results,
-                                     ref_len, read_len, read_count, ref_start, ref_end, word_num,
-                                     threshold, nullptr, 0, nullptr) != BGSA_HIP_OK)
+    const int w_dev = bgsa_hip_word_num(params.algo, ref_len, read_len, params.k);
+    const size_t groups = static_cast<size_t>(read_count) / HIP_V_NUM;
+    const size_t host_group_bytes = static_cast<size_t>(BGSA_CHAR_NUM) * w_host * 256;
+    const size_t dev_group_bytes = static_cast<size_t>(BGSA_CHAR_NUM) * w_dev * 256;
+    const size_t peq_bytes = host_group_bytes * groups;
+    const size_t res_bytes = static_cast<size_t>(ref_end - ref_start) * read_count * result_elem_size(params.algo);
+
+    // queries: upload when the bytes differ from what the device holds
+    if (g_host.reserve(&g_host.d_content, &g_host.cap_content, content_bytes + 8)) die("hip_cal_align_score");
+    if (g_host.content_copy.size() != content_bytes || memcmp(g_host.content_copy.data(), content, content_bytes) != 0) {
+        g_host.content_copy.assign(reinterpret_cast<unsigned char *>(content), reinterpret_cast<unsigned char *>(content) + content_bytes);
+        if (hipMemcpyAsync(g_host.d_content, g_host.content_copy.data(), content_bytes, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {   // content_copy is pageable: finish before it can change
+            set_error_text("hipMemcpy H2D (queries) failed");
+            die("hip_cal_align_score");
+        }
+    }
+
+    // Peq: a resident range, or the per-call mirror
+    const unsigned char *peq_host = reinterpret_cast<const unsigned char *>(preprocess_reads);
+    const hip_read_t *d_peq = nullptr;
+    for (ResidentRange &r : g_host.ranges) {
+        if (peq_host < r.host || peq_host + peq_bytes > r.host + r.bytes || r.w_host != w_host || r.w_dev != w_dev ||
+            (peq_host - r.host) % host_group_bytes != 0)
+            continue;
+        if (!r.uploaded || r.device != g_host.device) {
+            const size_t r_groups = r.bytes / host_group_bytes;
+            if (r.dev && r.device != g_host.device) { (void)hipFree(r.dev); r.dev = nullptr; }
+            if (!r.dev && hipMalloc(&r.dev, r_groups * dev_group_bytes) != hipSuccess) {
+                set_error_text("hipMalloc (resident bucket) failed");
+                die("hip_cal_align_score");
+            }
+            if (upload_peq(r.dev, r.host, r_groups, w_host, w_dev, s)) die("hip_cal_align_score");
+            r.device = g_host.device;
+            r.uploaded = true;
+            g_host.peq_uploads++;
+            g_host.peq_upload_bytes += r.bytes;
+        }
+        d_peq = reinterpret_cast<const hip_read_t *>(static_cast<unsigned char *>(r.dev) +
+                                                     (peq_host - r.host) / host_group_bytes * dev_group_bytes);
+        break;
+    }
+    if (!d_peq) {
+        if (g_host.reserve(&g_host.d_peq, &g_host.cap_peq, groups * dev_group_bytes)) die("hip_cal_align_score");
+        if (upload_peq(g_host.d_peq, preprocess_reads, groups, w_host, w_dev, s)) die("hip_cal_align_score");
+        g_host.peq_uploads++;
+        g_host.peq_upload_bytes += peq_bytes;
+        d_peq = static_cast<const hip_read_t *>(g_host.d_peq);
+    }
+    if (g_host.reserve(&g_host.d_results, &g_host.cap_results, res_bytes)) die("hip_cal_align_score");
+    if (bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_content), d_peq, g_host.d_results,
+                                    ref_len, read_len, read_count, ref_start, ref_end, w_dev,
+                                    nullptr, 0, s) != BGSA_HIP_OK)
         die("hip_cal_align_score");
-    hipError_t e = hipMemcpy(align_results, g_ws.d_results, res_bytes, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(align_results, g_host.d_results, res_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         set_error("hipMemcpy D2H", e, __FILE__, __LINE__);
         die("hip_cal_align_score");
     }
+    if (bgsa_hip_stream_faults(1) != 0) die("hip_cal_align_score");  // text set by stream_faults
 }
 
 void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_num,

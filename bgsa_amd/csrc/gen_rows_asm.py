@@ -47,7 +47,8 @@ S_BASE_LO, S_BASE_HI = "s64", "s65"
 S_PC, S_PC_LO, S_PC_HI = "s[66:67]", "s66", "s67"
 S_C = "s68"
 S_PTR, S_PTR_LO, S_PTR_HI = "s[70:71]", "s70", "s71"
-S_LEFT = "s69"  # windows this stream may still fetch: bounds the loop whatever bytes it reads
+S_LEFT = "s69"  # windows this stream may still fetch; handed back to the caller: >= 0 after a well-formed stream,
+                # -1 = the budget ran out before END, -2 = a byte that is no stream code (L_fail slots)
 CLOBBERS = ["s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
             "vcc", "scc", "memory"]
 
@@ -61,6 +62,16 @@ def dispatch() -> list[str]:
         f"s_addc_u32 {S_PC_HI}, {S_BASE_HI}, 0",
         f"s_setpc_b64 {S_PC}",
     ]
+
+
+def fail_slot() -> list[str]:
+    """Slot of a byte value that is no stream code: leave the loop and say so (S_LEFT = -2)."""
+    return [f"s_mov_b32 {S_LEFT}, -2", "s_branch L_done_%="]
+
+
+def done(wait: str = "s_waitcnt lgkmcnt(0)") -> list[str]:
+    """Common exit: every path out of the loop lands here; the caller gets S_LEFT (see above)."""
+    return ["L_done_%=:", wait, f"s_mov_b32 %[left], {S_LEFT}"]
 
 
 def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n_eq: int,
@@ -113,11 +124,15 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
         f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
     ]
     asm += dispatch()
-    asm.append("L_done_%=:")
-    asm.append("s_waitcnt lgkmcnt(0)")
+    asm.append("L_refill_end_%=:")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
+    asm.append("L_body7_%=:")  # the dispatch masks the code with 7: the one value that is no code lands here
+    asm += fail_slot()
+    asm += done()
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += ['[left] "=s"(left)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
     if n_planes:
         ins = [f'[b{j}] "v"(B[{j}])' for j in range(n_planes)]
@@ -132,17 +147,19 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
     return f"""
 // {body.valu_count()} VALU per row, {n_slots} temporaries, {nops} hazard nops
 template <>
-__device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
+__device__ __forceinline__ int {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
                                                    {masks_param},
                                                    const unsigned long long stream,
                                                    const int n_windows)
 {{
     uint32_t tmp[{max(n_slots, 1)}];
+    int left;
     asm volatile(
 {text}
         : {", ".join(outs)}
         : {", ".join(ins)}
         : {clob});
+    return left;
 }}
 """
 
@@ -214,11 +231,11 @@ def gen_pair_function(fn_name: str, template_args: str, body: R.Body, n_state: i
         f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
     ]
     asm += disp()
-    asm.append("L_done_%=:")
-    asm.append("s_waitcnt lgkmcnt(0)")
+    asm += done()   # the dispatch masks with 0x1f and all 32 slots exist: no byte value can leave the table
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += ['[left] "=s"(left)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
     ins = [f'[e{c}_{j}] "v"(P[{c}][{j}])' for c in range(5) for j in range(n_eq)]
     ins.append('[qp] "s"(stream)')
@@ -227,24 +244,26 @@ def gen_pair_function(fn_name: str, template_args: str, body: R.Body, n_state: i
     return f"""
 // two rows per token: {2 * body.valu_count()} VALU per token, {n_slots} temporaries
 template <>
-__device__ __forceinline__ void {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
+__device__ __forceinline__ int {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
                                                    const uint32_t (&P)[5][{n_eq}],
                                                    const unsigned long long stream,
                                                    const int n_windows)
 {{
     uint32_t tmp[{max(n_slots, 1)}];
+    int left;
     asm volatile(
 {text}
         : {", ".join(outs)}
         : {", ".join(ins)}
         : {clob});
+    return left;
 }}
 """
 
 
 def gen_banded_function(wide: bool) -> str:
     """Row loop of the banded kernel: 32-bit band word (k <= 15) or a 64-bit pair (k <= 31).  Same
-    threaded-code skeleton plus stream code 7 = EVENT (followed by an argument byte): test/latch the
+    threaded-code skeleton plus stream code 63 = EVENT (followed by an argument byte): test/latch the
     reject mask, reset the error count at row k, advance the match-string words every 32 rows
     (rows_ir.banded_tokens)."""
     body = R.banded_body64() if wide else R.banded_body()
@@ -276,7 +295,7 @@ def gen_banded_function(wide: bool) -> str:
         return reg
 
     def disp() -> list[str]:
-        # token codes 0..32 (bgsa_common.h: banded_stream_layout); slot stride = a two-row body
+        # token codes 0..31 and 63 (bgsa_common.h: banded_stream_layout); slot stride = a two-row body
         return [
             f"s_and_b32 {S_C}, {S_WIN_LO}, 0x3f",
             f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
@@ -342,7 +361,12 @@ def gen_banded_function(wide: bool) -> str:
     asm += disp()
     asm.append("L_end31_%=:")
     asm.append(pad(31))
-    asm.append("L_body32_%=:")  # EVENT <arg>
+    for slot in range(32, 63):   # the dispatch masks with 0x3f: every value that is no token lands in a fail slot
+        asm.append(f"L_body{slot}_%=:")
+        asm += fail_slot()
+        asm.append(f"L_end{slot}_%=:")
+        asm.append(pad(slot))
+    asm.append("L_body63_%=:")  # EVENT <arg>: the last slot, so it may be longer than the slot stride
     asm += [
         f"s_and_b32 {S_ARG}, {S_WIN_LO}, 0xff",
         f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
@@ -377,14 +401,13 @@ def gen_banded_function(wide: bool) -> str:
         "L_ev_out_%=:",
     ]
     asm += disp()
-    asm.append("L_done_%=:")
-    asm.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")
     asm.append(f"s_mov_b64 %[dead], {S_DEAD}")
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
     outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(n_m)]
-    outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)']
+    outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)', '[left] "=s"(left)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
     ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[mask] "s"(band_mask)', '[mask_hi] "s"(band_mask_hi)',
            '[thr] "s"(limit)']
@@ -395,12 +418,13 @@ def gen_banded_function(wide: bool) -> str:
 // state = {{VP, VN, errors since row k}} (VP lo/hi, VN lo/hi, errors when wide); M[c][..] = consecutive
 // 32-bit words of class c's offset match string (the last one is the prefetch target); voff = byte
 // offset of the next word to fetch relative to base[c]; returns the reject mask (lanes whose error
-// count passed `limit` at the last checkpoint, or all lanes if the wave stopped early).
+// count passed `limit` at the last checkpoint, or all lanes if the wave stopped early).  left = the
+// stream's remaining window budget, negative after a malformed stream (gen_rows_asm.py: S_LEFT).
 __device__ __forceinline__ unsigned long long banded_rows_asm{64 if wide else 32}(uint32_t (&state)[{n_state}], uint32_t (&M)[5][{n_m}], uint32_t &voff,
                                                               const unsigned long long (&base)[5],
                                                               const unsigned long long stream, const int n_windows,
                                                               const uint32_t band_mask, const uint32_t band_mask_hi,
-                                                              const uint32_t limit)
+                                                              const uint32_t limit, int &left)
 {{
     uint32_t tmp[{max(n_slots, 1)}];
     unsigned long long dead;
@@ -488,13 +512,12 @@ def gen_blocked_function(fn_name: str, nw: int, body: R.Body, n_base: int, n_cha
         asm.append(f"v_add_u32 %[voff], 0x{(-moved) & 0xFFFFFFFF:x}, %[voff]")
     asm.append("s_waitcnt vmcnt(0)")
     asm += dispatch()
-    asm.append("L_done_%=:")
-    asm.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")   # codes 0..7 all exist here (7 = CARRY)
 
     n_state = n_base + 2 * n_chains
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
-    outs += ['[voff] "+v"(voff)']
+    outs += ['[voff] "+v"(voff)', '[left] "=s"(left)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
     if n_planes:
         ins = [f'[b{j}] "v"(B[{j}])' for j in range(n_planes)]
@@ -508,16 +531,18 @@ def gen_blocked_function(fn_name: str, nw: int, body: R.Body, n_base: int, n_cha
     return f"""
 // {body.valu_count()} VALU per row, {n_slots} temporaries, {n_chains} carry chains, {nops} hazard nops
 template <>
-__device__ __forceinline__ void {fn_name}<{nw}>(uint32_t (&state)[{n_state}], {masks_param},
+__device__ __forceinline__ int {fn_name}<{nw}>(uint32_t (&state)[{n_state}], {masks_param},
                                                        uint32_t &voff, const unsigned long long carry_base,
                                                        const unsigned long long stream, const int n_windows)
 {{
     uint32_t tmp[{max(n_slots, 1)}];
+    int left;
     asm volatile(
 {text}
         : {", ".join(outs)}
         : {", ".join(ins)}
         : {clob});
+    return left;
 }}
 """
 
@@ -564,7 +589,7 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
              "// All rows of one query against one group.  state[w*kBitpalPlanes+i] = plane i of word w\n"
              "// (weight 2^i); P[c][w] = match mask of character class c.\n"
              "template <int NW>\n"
-             "__device__ __forceinline__ void bitpal_rows_asm(uint32_t (&state)[kBitpalPlanes * NW],\n"
+             "__device__ __forceinline__ int bitpal_rows_asm(uint32_t (&state)[kBitpalPlanes * NW],\n"
              "                                                const uint32_t (&P)[5][NW],\n"
              "                                                const unsigned long long stream, const int n_windows);\n"]
     for nw in plain:
@@ -573,7 +598,7 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
                  "// state = planes x NW, then the carry-in words, then the carry-out words; voff / carry_base as\n"
                  "// in myers_block_rows_asm ([32-row chunk][chain][64 lanes] dwords).\n"
                  "template <int NW>\n"
-                 "__device__ __forceinline__ void bitpal_block_rows_asm(uint32_t (&state)[kBitpalPlanes * NW + 2 * kBitpalChains],\n"
+                 "__device__ __forceinline__ int bitpal_block_rows_asm(uint32_t (&state)[kBitpalPlanes * NW + 2 * kBitpalChains],\n"
                  "                                                      const uint32_t (&P)[5][NW], uint32_t &voff,\n"
                  "                                                      const unsigned long long carry_base,\n"
                  "                                                      const unsigned long long stream, const int n_windows);\n")
@@ -594,7 +619,7 @@ def main() -> int:
              "// (8-byte aligned, wave-uniform) of the packed query stream; n_windows = windows the stream\n"
              "// holds minus one = REFILLs a well-formed stream performs (the loop never does more).\n"
              "template <int NW, int G>\n"
-             "__device__ __forceinline__ void myers_rows_asm(uint32_t (&state)[2 * G * NW],\n"
+             "__device__ __forceinline__ int myers_rows_asm(uint32_t (&state)[2 * G * NW],\n"
              "                                               const uint32_t (&P)[5][G * NW],\n"
              "                                               const unsigned long long stream, const int n_windows);\n"]
     for nw in MYERS_NW:  # G = 1 only: two groups per wave measured slower (fewer waves per SIMD)
@@ -602,14 +627,14 @@ def main() -> int:
     parts.append("\n// Short subjects: the row is so short that the scalar dispatch bounds the loop, so a stream token\n"
                  "// carries two rows (bgsa_common.h: pair_stream_window).\n"
                  "template <int NW>\n"
-                 "__device__ __forceinline__ void myers_pair_rows_asm(uint32_t (&state)[2 * NW],\n"
+                 "__device__ __forceinline__ int myers_pair_rows_asm(uint32_t (&state)[2 * NW],\n"
                  "                                                    const uint32_t (&P)[5][NW],\n"
                  "                                                    const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PAIR_NW:
         parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}", R.myers_body(nw, 1), 2 * nw, nw))
     parts.append("\n// Long subjects (NW 26..32; the widths below 26 serve the column-block kernel and A/B runs): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
                  "template <int NW>\n"
-                 "__device__ __forceinline__ void myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"
+                 "__device__ __forceinline__ int myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"
                  "                                                      const uint32_t (&B)[3 * NW],\n"
                  "                                                      const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PLANES_NW:
@@ -618,7 +643,7 @@ def main() -> int:
                  "// {VP, VN} x NW, carry-in words (add, HP, HN), carry-out words; voff = this lane's byte offset\n"
                  "// of the current 32-row chunk in the wave's carry buffer ([chunk][3][64] dwords at carry_base).\n"
                  "template <int NW>\n"
-                 "__device__ __forceinline__ void myers_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&B)[3 * NW],\n"
+                 "__device__ __forceinline__ int myers_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&B)[3 * NW],\n"
                  "                                                     uint32_t &voff, const unsigned long long carry_base,\n"
                  "                                                     const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_BLOCK_NW:
@@ -626,7 +651,7 @@ def main() -> int:
     parts.append("\n// The same with the five Peq planes of the block resident instead of the code planes: 10 VALU per word,\n"
                  "// narrower blocks (rows_ir.py: myers_peq_block_body).\n"
                  "template <int NW>\n"
-                 "__device__ __forceinline__ void myers_peq_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&P)[5][NW],\n"
+                 "__device__ __forceinline__ int myers_peq_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&P)[5][NW],\n"
                  "                                                         uint32_t &voff, const unsigned long long carry_base,\n"
                  "                                                         const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PEQ_BLOCK_NW:

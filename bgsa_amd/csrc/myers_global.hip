@@ -172,7 +172,7 @@ template <int NW, int G>
 __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes)
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
 {
     const int lane = threadIdx.x & (kLanes - 1);
     const int group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
@@ -203,10 +203,12 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
         }
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        int left;
         if constexpr (G == 1 && NW <= kPairMaxWords)  // short rows: two per stream token (launch_asm packs it so)
-            myers_pair_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+            left = myers_pair_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
         else
-            myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+            left = myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        note_stream_fault(fault_word, left);
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
             int score = ref_len;  // D[m][n] = m + sum over the n subject columns of (VP - VN)
@@ -230,7 +232,7 @@ template <int NW>
 __global__ __launch_bounds__(256) void myers_global_planes_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes)
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
 {
     const int lane = threadIdx.x & (kLanes - 1);
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
         }
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        myers_planes_rows_asm<NW>(st, Bp, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        note_stream_fault(fault_word, myers_planes_rows_asm<NW>(st, Bp, uniform_u64(s),
+                                                                __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
         int score = ref_len;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -282,7 +285,8 @@ template <int NW, bool PEQ = false>
 __global__ __launch_bounds__(256) void myers_blocked_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks, unsigned long long *task_counter)
+    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks, unsigned long long *task_counter,
+    unsigned *__restrict__ fault_word)
 {
     const int lane = threadIdx.x & (kLanes - 1);
     const int wave = threadIdx.x >> 6;
@@ -345,12 +349,14 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                     st[2 * NW + 3 + i] = 0u;
                 }
                 uint32_t voff = static_cast<uint32_t>(lane * 4);
+                int left;
                 if constexpr (PEQ)
-                    myers_peq_block_rows_asm<NW>(st, Pq, voff, carry_base, uniform_u64(s),
-                                                 __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                    left = myers_peq_block_rows_asm<NW>(st, Pq, voff, carry_base, uniform_u64(s),
+                                                        __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
                 else
-                    myers_block_rows_asm<NW>(st, Bp, voff, carry_base, uniform_u64(s),
-                                             __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                    left = myers_block_rows_asm<NW>(st, Bp, voff, carry_base, uniform_u64(s),
+                                                    __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+                note_stream_fault(fault_word, left);
                 // carry-out words of the last (possibly partial) chunk, first row left-aligned
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
@@ -420,10 +426,13 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream)
                         : launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream))
         return rc;
+    const int stride = static_cast<int>(kPairs ? pair_stream_stride(ref_len) : stream_stride(ref_len));
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, stride, kPairs ? kPairRefill : kCodeRefill, kPairs ? -1 : 7, stream, &fault)) return rc;
     hipLaunchKernelGGL((myers_global_asm_kernel<NW, G>), grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, static_cast<int>(kPairs ? pair_stream_stride(ref_len) : stream_stride(ref_len)));
+                       nq, q_tile, stride, fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -444,10 +453,12 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
         return BGSA_HIP_EUNSUPPORTED;
     }
     if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
     hipLaunchKernelGGL((myers_global_planes_kernel<NW>), grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, static_cast<int>(stream_stride(ref_len)));
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -465,11 +476,13 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     unsigned long long *counter = reinterpret_cast<unsigned long long *>(
         reinterpret_cast<unsigned char *>(carry) + blocked_carry_bytes(ref_len, 3));
     BGSA_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, stride, kCodeRefill, -1, stream, &fault)) return rc;
     hipLaunchKernelGGL((myers_blocked_kernel<NW, PEQ>), dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
                        blocked_q_tile(nq, read_count / kLanes),
-                       stride, n_blocks, counter);
+                       stride, n_blocks, counter, fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -575,10 +588,14 @@ int pick_peq_nw(int word_num)
     return -1;
 }
 
-const char *myers_kernel_name(int word_num)
+const char *myers_kernel_name(int word_num, int semi_global)
 {
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
+    if (semi_global) {
+        snprintf(name, sizeof name, "myers_global_kernel<%d, 1, true>", nw);
+        return name;
+    }
     if (word_num > myers_max_plain_words()) {
         int n_blocks = 0;
         if (peq_blocks())

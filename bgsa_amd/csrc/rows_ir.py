@@ -583,13 +583,13 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
     return out
 
 
-BANDED_SINGLE, BANDED_END, BANDED_REFILL, BANDED_EVENT = 25, 30, 31, 32
+BANDED_SINGLE, BANDED_END, BANDED_REFILL, BANDED_EVENT = 25, 30, 31, 63
 
 
 def banded_stream_bytes(length: int, k: int, codes) -> list:
     """The packed banded stream, byte for byte as bgsa_common.h: banded_stream_layout() writes it:
     banded_tokens() with two consecutive rows folded into one token (5*a + b) wherever no event sits
-    between them, one-row tokens 25 + c otherwise, EVENT = {32, bits}, 7 payload bytes + REFILL per
+    between them, one-row tokens 25 + c otherwise, EVENT = {63, bits}, 7 payload bytes + REFILL per
     8-byte window, a two-byte token never split across windows, END padding and one spare END window."""
     out, slot = [], 0
 

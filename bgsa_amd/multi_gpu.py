@@ -94,6 +94,153 @@ class RatioBalancer:
         return new
 
 
+class ScoreGatherStream:
+    """The per-block score gather of a sharded run, streamed beside the kernels (C3 of SURVEY.md §2a).
+
+    The reference's KNC host downloads every device's [queries-of-the-block, its subjects] result tile
+    and appends them to the result file device after device (cal_mic.c:139-147, 535-536).  Here every
+    rank hands the tile of a finished query block to `submit()`; a side stream waits for the kernel
+    that produced it, and the tile goes to rank 0 with grouped point-to-point operations — each peer
+    straight into its own segment of root's block buffer, which IS the reference's per-device block
+    layout, so nothing is staged `world` times and nothing is padded to the widest shard.  Two block
+    buffers alternate: while block i travels, the compute stream is already scoring block i+1; the
+    caller's stream never waits for a transfer.  xGMI is point to point: the seven peers of an 8-GPU
+    node reach root over seven different links at once.
+
+    layout "device_blocks": root's buffer for one block = device 0's [rows, count_0], device 1's
+    [rows, count_1], ... flat (what `result` holds, with `.info` recording the counts);
+    layout "row_major": root additionally copies the segments into one [rows, sum(counts)] tile.
+    """
+
+    def __init__(self, dist, device, counts, dtype, block_rows: int, layout: str = "device_blocks", depth: int = 2,
+                 on_block=None):
+        """on_block(index, tensor): called on rank 0, in submission order, once block `index` is complete in
+        the chosen layout (the tensor is only valid during the call: a consumer copies it out, e.g. to the
+        pinned buffer its writer thread drains)."""
+        import torch
+        self.on_block = on_block
+        self.unflushed = {}    # slot -> (block index, rows)
+        self.torch = torch
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.device = torch.device(device)
+        self.counts = [int(c) for c in counts]
+        if len(self.counts) != self.world:
+            raise ValueError("need one subject count per rank")
+        if layout not in ("device_blocks", "row_major"):
+            raise ValueError("layout must be device_blocks or row_major")
+        self.layout, self.dtype, self.block_rows, self.depth = layout, dtype, int(block_rows), int(depth)
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        total = sum(self.counts)
+        self.offsets = [sum(self.counts[:r]) * self.block_rows for r in range(self.world)]
+        if self.rank == 0:
+            self.blocks = [torch.empty(self.block_rows * total, dtype=dtype, device=self.device) for _ in range(self.depth)]
+            self.tiles = ([torch.empty((self.block_rows, total), dtype=dtype, device=self.device) for _ in range(self.depth)]
+                          if layout == "row_major" else None)
+        else:   # a peer only needs a contiguous copy of its tile when the caller's view is strided
+            self.staging = [None] * self.depth
+        self.pending = [[] for _ in range(self.depth)]   # outstanding transfers per slot
+        self.n_submitted = 0
+        self.blocks_checked = 0
+        self.last = None    # root: (slot, rows) of the most recent block
+
+    def _wait_slot(self, slot):
+        for w in self.pending[slot]:
+            w.wait()
+        self.pending[slot] = []
+        if slot in self.unflushed:
+            index, rows = self.unflushed.pop(slot)
+            if self.on_block is not None:
+                if self.cuda:
+                    self.side.synchronize()      # the consumer reads the block from the host side
+                self.on_block(index, self._view(slot, rows))
+
+    def _view(self, slot, rows):
+        if self.layout == "row_major":
+            return self.tiles[slot][:rows]
+        return self.blocks[slot][: rows * sum(self.counts)]
+
+    def submit(self, tile):
+        """tile: this rank's [rows <= block_rows, count_rank] scores of one query block (device tensor, may
+        be a strided view).  Returns at once; the tile must stay untouched until drain() or until
+        `depth` further blocks have been submitted."""
+        torch = self.torch
+        rows = int(tile.shape[0])
+        if rows > self.block_rows or int(tile.shape[1]) != self.counts[self.rank]:
+            raise ValueError("tile does not match this rank's shard")
+        slot = self.n_submitted % self.depth
+        self.n_submitted += 1
+        ready = None
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+        ctx = torch.cuda.stream(self.side) if self.cuda else _null()
+        with ctx:
+            if self.cuda:
+                self.side.wait_event(ready)          # the kernel that wrote the tile
+            self._wait_slot(slot)                    # the slot's previous block has left / arrived
+            ops = []
+            if self.rank == 0:
+                buf = self.blocks[slot]
+                seg = lambda r: buf[self.offsets[r] * rows // self.block_rows: self.offsets[r] * rows // self.block_rows + rows * self.counts[r]]
+                seg(0).view(rows, self.counts[0]).copy_(tile, non_blocking=True)
+                for r in range(1, self.world):
+                    if self.counts[r]:
+                        ops.append(self.dist.P2POp(self.dist.irecv, seg(r).view(torch.uint8), r))
+                self.last = (slot, rows)
+            elif self.counts[self.rank]:
+                src = tile
+                if not tile.is_contiguous():
+                    if self.staging[slot] is None:
+                        self.staging[slot] = torch.empty((self.block_rows, self.counts[self.rank]), dtype=self.dtype, device=self.device)
+                    src = self.staging[slot][:rows]
+                    src.copy_(tile, non_blocking=True)
+                ops.append(self.dist.P2POp(self.dist.isend, src.reshape(-1).view(torch.uint8), 0))
+            if ops:
+                self.pending[slot] = self.dist.batch_isend_irecv(ops)
+            if self.rank == 0 and self.layout == "row_major":
+                for w in self.pending[slot]:
+                    w.wait()
+                self.pending[slot] = []
+                col = 0
+                for r in range(self.world):
+                    c = self.counts[r]
+                    start = self.offsets[r] * rows // self.block_rows
+                    self.tiles[slot][:rows, col:col + c].copy_(self.blocks[slot][start:start + rows * c].view(rows, c), non_blocking=True)
+                    col += c
+            if self.rank == 0:
+                self.unflushed[slot] = (self.n_submitted - 1, rows)
+
+    def drain(self):
+        """Waits for every outstanding block (host-side)."""
+        torch = self.torch
+        ctx = torch.cuda.stream(self.side) if self.cuda else _null()
+        with ctx:
+            order = sorted(range(self.depth), key=lambda sl: self.unflushed.get(sl, (1 << 60, 0))[0])
+            for slot in order:                       # flush in submission order
+                self._wait_slot(slot)
+        if self.cuda:
+            self.side.synchronize()
+        self.blocks_checked = self.n_submitted
+
+    def last_block(self):
+        """Root, after drain(): the most recent block in the chosen layout."""
+        if self.rank != 0 or self.last is None:
+            return None
+        slot, rows = self.last
+        return self._view(slot, rows)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class ShardedAligner:
     def __init__(self, dist=None, device=None, score_fn=None, algo: int = 0, k: int = 0, scores=None,
                  semi_global: bool = False):
@@ -160,6 +307,28 @@ class ShardedAligner:
         if layout == "row_major":
             return torch.cat(parts, dim=1)
         return torch.cat([p.reshape(-1) for p in parts])
+
+    def run_streamed(self, queries, subjects_all, block_rows: int = 100, layout: str = "device_blocks", ratios=None,
+                     score_block=None):
+        """The bucket scored block by block (block_rows queries, the reference's REF_BUCKET_COUNT) with the
+        gather of block i streamed beside the scoring of block i+1 (ScoreGatherStream).  Returns, on rank 0,
+        the list of per-block results in `layout` (host numpy arrays), else None; and the shards.
+        score_block(q_block, subjects_slice) -> [rows, count] tensor defaults to score_fn."""
+        torch = self.torch
+        q = self.broadcast_queries(queries)
+        shards = plan_shards(subjects_all.shape[0], self.world, ratios)
+        mine = shards[self.rank]
+        sub = subjects_all[mine.start: mine.start + mine.count]
+        fn = score_block if score_block is not None else self.score_fn
+        blocks = []
+        first = fn(q[:min(block_rows, q.shape[0])], sub)
+        gs = ScoreGatherStream(self.dist, first.device, [s.count for s in shards], first.dtype, block_rows, layout,
+                               on_block=lambda i, t: blocks.append(t.cpu().numpy().copy()))
+        gs.submit(first)
+        for lo in range(block_rows, q.shape[0], block_rows):
+            gs.submit(fn(q[lo:lo + block_rows], sub))
+        gs.drain()
+        return (blocks if self.rank == 0 else None), shards
 
     # ---- one bucket end to end ------------------------------------------------------------------------
     def run(self, queries: np.ndarray | None, subjects_all: np.ndarray, gather: bool = True,

@@ -86,7 +86,7 @@ void free_mem(void *mem);
 int bgsa_hip_select_algorithm(int algo);
 int bgsa_hip_current_algorithm(void);
 
-/* BitPAl with other integer scores (match > mismatch >= 2*gap, gap < 0).  The reference emits one
+/* BitPAl with other integer scores (match > mismatch, gap < 0).  The reference emits one
  * align_core.c per score set with its generator (`java -jar generator.jar -M -I -G`, README.md:26-82,
  * generator/.../BitPAlGenerator.java) and is rebuilt for it; this library is built with a list of
  * sets (`make -C bgsa_amd/csrc BITPAL_SETS="2,-3,-5 1,-3,-2 ..."`, gen_bitpal_sets.py) and picks the
@@ -98,6 +98,10 @@ int bgsa_hip_current_algorithm(void);
  * columns) of that set's kernel.  Any out-pointer may be NULL.
  * Like the generator (commonFactor, Main.java:213-267), scores with a common factor f run on the set
  * (M/f, I/f, G/f) and the result is multiplied by f: 4/-6/-10 needs only 2/-3/-5 compiled in.
+ * A mismatch below 2*gap can never be taken (two gaps are cheaper), so such a set runs as its
+ * mismatch = 2*gap instance: 1/-9/-2 needs 1/-4/-2.  A set that reduces to 0/-1/-1 — minus the edit
+ * distance times f, the generator's isEdit case (Main.java:270-271) — runs, in global mode, on the Myers
+ * kernels (10 instructions per word against 22) and needs no compiled BitPAl set at all.
  * bgsa_hip_select_scores(0, 1, 1) is the generator's `-m 1`: BGSA_ALGO_MYERS reporting +distance
  * instead of -distance (the same ints written directly while Myers is selected do the same). */
 int bgsa_hip_select_scores(int match, int mismatch, int gap);
@@ -118,23 +122,57 @@ enum { BGSA_ALIGN_GLOBAL = 0, BGSA_ALIGN_SEMIGLOBAL = 1 };
 int bgsa_hip_select_alignment(int mode);
 int bgsa_hip_current_alignment(void);
 
-/* word_num for the selected algorithm (what cal_<arch>.c computes at cal_cpu.c:252-256, banded
- * cal_cpu.c:253-254). */
+/* Every parameter the scoring call reads, as one value.  The reference keeps them in globals of the
+ * backend (the five ints, `threshold`); bgsa_hip_cal_align_score_dev() and the host seams snapshot those
+ * globals once per call, and callers that must not share process-wide state (two pipelines with
+ * different scores in one process) pass their own through the *_ex entry points instead. */
+typedef struct bgsa_hip_params {
+    int algo;                 /* BGSA_ALGO_* */
+    int alignment;            /* BGSA_ALIGN_* */
+    int match, mismatch, gap; /* BitPAl scores; Myers: (0,1,1) = +distance, anything else -distance */
+    int k;                    /* banded threshold */
+} bgsa_hip_params_t;
+int bgsa_hip_current_params(bgsa_hip_params_t *out);   /* the process-global selection, as of now */
+
+/* word_num of this backend's layouts: Myers / BitPAl ceil(subject_len / 32) (cal_cpu.c:252-253 with
+ * full_bits); banded ceil(subject_len / 32) + 3 words of the offset match string (the host seams also
+ * accept the reference's own banded value, banded/BGSA_CPU/cal_cpu.c:253-254 — see hip_handle_reads). */
 int bgsa_hip_word_num(int algo, int query_len, int subject_len, int k);
 /* hip_read_t elements per group of HIP_V_NUM subjects = BGSA_CHAR_NUM * word_num * HIP_V_NUM. */
 size_t bgsa_hip_group_words(int algo, int word_num, int k);
 
 /* ---- BGSA backend surface (host buffers) ---------------------------------------------------
- * align_hip / hip_cal_align_score share one grow-only device workspace inside the library and take
- * turns on it: they may be called from several host threads, as the reference's OpenMP loop calls
- * align_<arch> (cal_cpu.c:63-84), but the calls are serialised.  bgsa_hip_release_workspace() frees
- * that workspace. */
+ * align_hip / hip_cal_align_score share one set of device mirrors inside the library and take turns on
+ * it: they may be called from several host threads, as the reference's OpenMP loop calls align_<arch>
+ * (cal_cpu.c:63-84), but the calls are serialised; each call reads the global selection (algorithm,
+ * scores, alignment mode, threshold) once, under that lock.  bgsa_hip_release_workspace() frees the
+ * mirrors.
+ *
+ * Resident buckets.  hip_handle_reads() remembers the host range it filled; the first scoring call on
+ * that range uploads it, later calls on it (the reference scores 100 queries per call against the same
+ * bucket, cal_cpu.c:363-401) reuse the device copy until hip_handle_reads() writes the range again —
+ * the KNC backend's `nocopy ... RETAIN` (BGSA_KNC/cal_mic.c:348-356).  The query buffer is uploaded
+ * only when its bytes changed.  A host that fills Peq words by other means must either call
+ * bgsa_hip_bucket_resident() after every change or switch the mechanism off with
+ * bgsa_hip_set_auto_resident(0) (upload on every call, the stateless contract of the CPU backends).
+ * malloc_mem() hands out page-locked memory for large blocks, so every buffer of the reference's
+ * pipeline (cal_cpu.c:206-267) moves at full PCIe rate. */
+int bgsa_hip_set_auto_resident(int on);
+/* host_peq[0 .. bytes) holds whole groups in the library's own layout with word_num words. */
+int bgsa_hip_bucket_resident(const hip_read_t *host_peq, size_t bytes, int word_num);
+int bgsa_hip_bucket_release(const hip_read_t *host_peq);   /* NULL: all of them */
+/* Counters of the seams since process start (any pointer may be NULL). */
+int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_upload_bytes);
 
 /* ASCII rows -> Peq blocks, layout [group][char 0..4][word][lane 0..63]
  * (replaces cpu_handle_reads, reference original/BGSA_CPU/global.c:25-70; for BGSA_ALGO_BANDED
  * the words hold the match string offset by threshold+1 bits, which is what the windows of
  * banded/BGSA_CPU/global.c:25-84 + align_core.c:35-62 slide over).  result_reads must be zeroed by the caller (cal_cpu.c:273)
- * and read_count must be a multiple of HIP_V_NUM (file.c:84-112 pads with all-'N' reads). */
+ * and read_count must be a multiple of HIP_V_NUM (file.c:84-112 pads with all-'N' reads).
+ * word_num = bgsa_hip_word_num(); for BGSA_ALGO_BANDED also the reference's own value,
+ * (len - h + 63)/64 + 1 words of its 64-bit cpu_read_t (banded/BGSA_CPU/cal_cpu.c:253-254): that
+ * buffer holds the same bit string without the trailing zero words, and hip_cal_align_score / align_hip
+ * called with the same word_num re-pitch it on upload — so banded/BGSA_CPU's host files work unchanged. */
 void hip_handle_reads(seq_t *read_seq, hip_read_t *result_reads, int word_num,
                       int64_t read_start, int64_t read_count);
 
@@ -177,6 +215,13 @@ int bgsa_hip_memset(void *dst, int value, size_t bytes, void *stream);
 int bgsa_hip_stream_create(void **stream);   /* on the current device */
 int bgsa_hip_stream_destroy(void *stream);
 int bgsa_hip_stream_synchronize(void *stream);
+/* Events: per-device kernel times for the dynamic balancing of the command line (BGSA_KNC/global.c:120-168). */
+int bgsa_hip_event_create(void **event);
+int bgsa_hip_event_destroy(void *event);
+int bgsa_hip_event_record(void *event, void *stream);
+int bgsa_hip_event_synchronize(void *event);
+int bgsa_hip_event_elapsed_ms(void *start, void *stop, float *ms);
+int bgsa_hip_stream_wait_event(void *stream, void *event);
 
 /* Subject preprocess ON the GPU: d_rows = read_count rows of (len+1) ASCII bytes in device
  * memory -> d_peq in the layout above.  read_count must be a multiple of HIP_V_NUM.
@@ -200,12 +245,35 @@ size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queri
  * d_peq = Peq blocks of read_count subjects; d_results = [ref_end-ref_start][read_count]
  * (int16, or int8 for banded).  d_workspace = caller-owned device scratch of at least
  * bgsa_hip_workspace_bytes(algo, ref_len, read_len, ref_end-ref_start) bytes, or NULL to let the library
- * keep a grow-only scratch of its own (allocates on first use: not graph-capture safe).
+ * keep a grow-only scratch of its own per (device, stream) (allocates on first use: not graph-capture
+ * safe; calls that use it are serialised among themselves).  word_num must be bgsa_hip_word_num().
+ * Reads the process-global selection (scores, alignment mode) once, at entry.
  * All pointers are device pointers; asynchronous on `stream`. */
 int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read_t *d_peq,
                                  void *d_results, int ref_len, int read_len, int64_t read_count,
                                  int ref_start, int ref_end, int word_num, int k,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The same with the parameters passed explicitly instead of read from the process globals. */
+size_t bgsa_hip_workspace_bytes_ex(const bgsa_hip_params_t *params, int ref_len, int read_len, int n_queries);
+int bgsa_hip_cal_align_score_ex(const bgsa_hip_params_t *params, const char *d_content, const hip_read_t *d_peq,
+                                void *d_results, int ref_len, int read_len, int64_t read_count,
+                                int ref_start, int ref_end, int word_num,
+                                void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Stream faults.  The kernels walk each query as a packed code stream (below) under a window budget; a
+ * wave whose stream ends without an END token, or holds a byte that is no token, leaves its loop and
+ * raises a bit in a sticky per-device word instead of storing a score.  A well-formed stream cannot do
+ * either: a set bit means the stream bytes were damaged between the packer and the row loop, and the
+ * scores of that call are not to be trusted.  bgsa_hip_stream_faults() returns the word of the current
+ * device (0 = clean; call after synchronising the streams that scored) and optionally clears it; the
+ * host-buffer seams check it after every call and fail loudly.
+ * bgsa_hip_debug_inject_stream_fault(kind): tests only — the next scoring launch of this process has
+ * its first stream overwritten with REFILL tokens (1) or with a byte that is no token (2). */
+#define BGSA_HIP_FAULT_BUDGET 1
+#define BGSA_HIP_FAULT_CODE 2
+int bgsa_hip_stream_faults(int clear);
+int bgsa_hip_debug_inject_stream_fault(int kind);
 
 /* Introspection (host only, no GPU): the packed code stream the kernels walk for one mapped query
  * row, 8-byte windows of 7 tokens + REFILL.  Myers / BitPAl: codes 0..4 = row of that character
@@ -213,7 +281,7 @@ int bgsa_hip_cal_align_score_dev(int algo, const char *d_content, const hip_read
  * kernel (subjects > 1024 bp: a CARRY token, code 7, in front of every 32nd row) and k = -2 the
  * two-rows-per-token stream of the <= 64 bp kernels (codes as for banded below, without EVENT).
  * BGSA_ALGO_BANDED (threshold k): 0..24 = two rows of classes a, b as 5*a + b, 25..29 = one row,
- * 30 = END, 31 = REFILL, 32 = EVENT + argument byte (1 reset the error count, 2 advance the match
+ * 30 = END, 31 = REFILL, 63 = EVENT + argument byte (1 reset the error count, 2 advance the match
  * words, 4 test the limit, 8 latch the reject mask).
  * Writes at most `cap` bytes to dst (may be NULL) and returns the stream length in bytes. */
 int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, unsigned char *dst, int cap);

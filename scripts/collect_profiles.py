@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Copy the judged summaries of one scripts/gpu_round_report.sh run from gpurun_out/<tag>/ into
 profiles/ under <prefix>_*: bench lines, rocprofv3 kernel stats, per-launch PMC values of the
-dominant kernel, the GPU test log and the microbenchmark outputs.
+dominant kernel of every config (and, for config 3, of every subject mix), the GPU test log and the
+microbenchmark outputs.
 
-    python3 scripts/collect_profiles.py gpurun_out/r01_v7 r01_v7
+    python3 scripts/collect_profiles.py gpurun_out/r02 r02
 """
 import csv
 import glob
 import json
+import re
 import shutil
 import sys
 from pathlib import Path
@@ -15,6 +17,7 @@ from pathlib import Path
 src, prefix = Path(sys.argv[1]), sys.argv[2]
 dst = Path(__file__).resolve().parent.parent / "profiles"
 dst.mkdir(exist_ok=True)
+HELPERS = ("pack", "preprocess", "map_queries", "scale_scores", "corrupt_stream")
 
 for c in (2, 3, 4, 5):
     b = src / f"bench_cfg{c}.json"
@@ -26,33 +29,39 @@ for c in (2, 3, 4, 5):
     if stats:
         shutil.copy(stats[0], dst / f"{prefix}_cfg{c}_kernel_stats.csv")
 
-# PMC: value per launch of the kernel with the largest total (the dominant kernel of the bench line)
-rows = []
-for d in sorted(glob.glob(str(src / "pmc_*"))):
-    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-    if not files:
-        continue
-    per = {}
-    for r in csv.DictReader(open(files[0])):
-        if "bgsa::" not in r["Kernel_Name"] or "pack" in r["Kernel_Name"] or "preprocess" in r["Kernel_Name"] \
-                or "map_queries" in r["Kernel_Name"]:
+# PMC: value per launch of the scoring kernel, one file per config (and banded mix)
+groups = {}
+for d in sorted(glob.glob(str(src / "pmc_cfg*"))):
+    m = re.match(r"pmc_(cfg\d(?:_(?:planted|random|dense1pct|survivors))?)_(\w+)$", Path(d).name)
+    if m and Path(d).is_dir():
+        groups.setdefault(m.group(1), []).append(d)
+for key, dirs in groups.items():
+    rows = []
+    for d in dirs:
+        files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+        if not files:
             continue
-        key = (r["Counter_Name"], r["Kernel_Name"].split("(")[0])
-        tot, n = per.get(key, (0.0, set()))
-        n.add(r["Dispatch_Id"])
-        per[key] = (tot + float(r["Counter_Value"]), n)
-    for (ctr, kern), (tot, disp) in sorted(per.items()):
-        note = ""
-        if ctr == "FETCH_SIZE":
-            note = "KB; gfx950 counts 64 B per 128-B request on coalesced reads (MI355X_MICROARCH.md): x2"
-        if ctr == "WRITE_SIZE":
-            note = "KB"
-        rows.append((Path(d).name, ctr, f"{tot / len(disp):.0f}", kern, note))
-if rows:
-    with open(dst / f"{prefix}_cfg2_pmc.csv", "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["pass", "counter", "value_per_launch", "kernel", "note"])
-        w.writerows(rows)
+        per = {}
+        for r in csv.DictReader(open(files[0])):
+            name = r["Kernel_Name"]
+            if "bgsa::" not in name or any(h in name for h in HELPERS):
+                continue
+            k = (r["Counter_Name"], name.split("(")[0])
+            tot, n = per.get(k, (0.0, set()))
+            n.add(r["Dispatch_Id"])
+            per[k] = (tot + float(r["Counter_Value"]), n)
+        for (ctr, kern), (tot, disp) in sorted(per.items()):
+            note = ""
+            if ctr == "FETCH_SIZE":
+                note = "KB; gfx950 counts 64 B per 128-B request on coalesced reads (MI355X_MICROARCH.md): x2"
+            if ctr == "WRITE_SIZE":
+                note = "KB"
+            rows.append((Path(d).name, ctr, f"{tot / len(disp):.0f}", kern, note))
+    if rows:
+        with open(dst / f"{prefix}_{key}_pmc.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["pass", "counter", "value_per_launch", "kernel", "note"])
+            w.writerows(rows)
 
 for name, out in (("pytest_gpu.log", f"{prefix}_pytest_gpu.log"), ("ubench_valu_rate.txt", f"{prefix}_ubench_valu_rate.txt"),
                   ("ubench_body_rate.txt", f"{prefix}_ubench_body_rate.txt"), ("ubench_operand_cost.txt", f"{prefix}_ubench_operand_cost.txt"),

@@ -1,30 +1,55 @@
 #!/bin/bash
-# Full GPU record for profiles/: tests, the four BASELINE configs with CPU baselines, rocprofv3 stats.
-# Run on the GPU box from the repo root:  bash scripts/gpu_round_report.sh <tag>
-tag=${1:-r01_v7}
+# GPU record for profiles/: the GPU tests, the four BASELINE configs with CPU baselines, rocprofv3 kernel
+# stats and PMC passes per config (separate --pmc runs, as MI355X_MICROARCH.md §HBM prescribes).
+# Run on the GPU box from the repo root:  bash scripts/gpu_round_report.sh <tag> [parts]
+#   parts: any of  tests bench prof pmc banded ubench  (default: all)
+tag=${1:-r02}
+parts=${2:-"tests bench prof pmc banded"}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
+has() { case " $parts " in *" $1 "*) return 0;; *) return 1;; esac; }
 # a step that had to be killed says something about the GPU: stop, do not start the next one
 guard() { if [ "$1" = 124 ] || [ "$1" = 137 ]; then echo "step killed (rc=$1): stopping" | tee -a $out/summary.txt; exit 1; fi; }
-timeout -k 10 500 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc" | tee -a $out/summary.txt; guard $rc
-timeout -k 10 400 python bench.py --config 2 > $out/bench_cfg2.json 2> $out/bench_cfg2.err; rc=$?; echo "cfg2 rc=$rc" | tee -a $out/summary.txt; guard $rc
-timeout -k 10 400 python bench.py --config 3 --cpu-sample 2000x100000 > $out/bench_cfg3.json 2> $out/bench_cfg3.err; rc=$?; echo "cfg3 rc=$rc" | tee -a $out/summary.txt; guard $rc
-timeout -k 10 500 python bench.py --config 4 --cpu-sample 1000x50000 > $out/bench_cfg4.json 2> $out/bench_cfg4.err; rc=$?; echo "cfg4 rc=$rc" | tee -a $out/summary.txt; guard $rc
-timeout -k 10 400 python bench.py --config 5 --cpu-sample 200x20000 > $out/bench_cfg5.json 2> $out/bench_cfg5.err; rc=$?; echo "cfg5 rc=$rc" | tee -a $out/summary.txt; guard $rc
-for c in 2 3 4 5; do
-  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $out/prof_cfg$c.log 2>&1
-  rc=$?; echo "prof cfg$c rc=$rc" | tee -a $out/summary.txt; guard $rc
-done
-# PMC passes for the headline config (separate runs, as MI355X_MICROARCH.md §HBM prescribes)
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_$ctr -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_$ctr.log 2>&1
-  rc=$?; echo "pmc $ctr rc=$rc" | tee -a $out/summary.txt; guard $rc
-done
-timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc_SQ -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pmc_SQ.log 2>&1
-rc=$?; echo "pmc SQ rc=$rc" | tee -a $out/summary.txt; guard $rc
-# issue-rate microbenchmarks behind DESIGN.md §4.1
-( cd scripts/ubench && ./valu_rate 8 2000 > ../../$out/ubench_valu_rate.txt 2>&1; ./body_rate 20000 > ../../$out/ubench_body_rate.txt 2>&1; ./bank_conflict 4 4000 > ../../$out/ubench_operand_cost.txt 2>&1 )
-# every compiled BitPAl score set
-timeout -k 10 400 bash scripts/bitpal_sets_bench.sh $tag > $out/bitpal_sets.log 2>&1; cp gpurun_out/bitpal_sets_$tag.jsonl $out/bitpal_sets.jsonl 2>/dev/null
-tail -c 300 $out/pytest_gpu.log
+step() { # step <name> <seconds> <cmd...>  -> runs under timeout, logs rc
+  local name=$1 secs=$2; shift 2
+  timeout -k 10 $secs "$@"; local rc=$?
+  echo "$name rc=$rc" | tee -a $out/summary.txt; guard $rc
+}
+if has tests; then
+  step pytest 1000 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1
+  tail -n 3 $out/pytest_gpu.log
+fi
+if has bench; then
+  step cfg2 500 python bench.py --config 2 > $out/bench_cfg2.json 2> $out/bench_cfg2.err
+  step cfg3 500 python bench.py --config 3 --cpu-sample 2000x100000 > $out/bench_cfg3.json 2> $out/bench_cfg3.err
+  step cfg4 600 python bench.py --config 4 --cpu-sample 1000x50000 > $out/bench_cfg4.json 2> $out/bench_cfg4.err
+  step cfg5 600 python bench.py --config 5 --steps 2 --cpu-sample 200x20000 > $out/bench_cfg5.json 2> $out/bench_cfg5.err
+fi
+if has prof; then
+  for c in 2 3 4 5; do
+    step "prof cfg$c" 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-total --banded-variants '' > $out/prof_cfg$c.log 2>&1
+  done
+fi
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU"
+if has pmc; then
+  for c in 2 4 5; do
+    for grp in FETCH_SIZE WRITE_SIZE SQ; do
+      ctrs=$grp; [ $grp = SQ ] && ctrs=$SQ
+      step "pmc cfg$c $grp" 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc_cfg${c}_$grp -- python3 bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-total > $out/pmc_cfg${c}_$grp.log 2>&1
+    done
+  done
+fi
+if has banded; then
+  for mix in planted random dense1pct survivors; do
+    for grp in FETCH_SIZE WRITE_SIZE SQ; do
+      ctrs=$grp; [ $grp = SQ ] && ctrs=$SQ
+      step "pmc cfg3 $mix $grp" 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc_cfg3_${mix}_$grp -- python3 bench.py --config 3 --banded-mix $mix --banded-variants '' --steps 1 --warmup 1 --no-cpu-baseline --no-total > $out/pmc_cfg3_${mix}_$grp.log 2>&1
+    done
+  done
+fi
+if has ubench; then
+  ( cd scripts/ubench && ./valu_rate 8 2000 > ../../$out/ubench_valu_rate.txt 2>&1; ./body_rate 20000 > ../../$out/ubench_body_rate.txt 2>&1; ./bank_conflict 4 4000 > ../../$out/ubench_operand_cost.txt 2>&1 )
+  step bitpal_sets 400 bash scripts/bitpal_sets_bench.sh $tag > $out/bitpal_sets.log 2>&1; cp gpurun_out/bitpal_sets_$tag.jsonl $out/bitpal_sets.jsonl 2>/dev/null
+fi
+echo done | tee -a $out/summary.txt

@@ -123,7 +123,7 @@ def _decode_banded_stream(raw):
         elif code == 31:
             win, pos = win + 1, 0
         else:
-            assert code == 32
+            assert code == 63   # EVENT: the last of the 64 dispatch slots
             tokens.append(("event", int(raw[base + pos])))
             pos += 1
         assert pos <= 8
@@ -234,7 +234,15 @@ def test_scores_with_a_common_factor_use_the_reduced_set(L):
     assert L.bgsa_hip_select_scores(4, -6, -11) != 0           # no common factor, and not compiled
     assert ints() == [6, -9, -15]
     assert L.bgsa_hip_select_scores(1, 1, -1) != 0 and b"match > mismatch" in L.bgsa_hip_last_error()
-    assert L.bgsa_hip_select_scores(2, -9, -4) != 0            # mismatch below two gaps: outside the method
+    # a mismatch below two gaps is never taken: 2/-9/-4 runs as 2/-8/-4 = 2 x (1/-4/-2)
+    if (1, -4, -2) in B.score_sets():
+        assert L.bgsa_hip_select_scores(2, -9, -4) == 0 and ints() == [2, -9, -4]
+        assert L.bgsa_hip_kernel_name(B.ALGO_BITPAL, 5).startswith(b"bitpal_asm_kernel<5>")
+    assert L.bgsa_hip_select_scores(3, -50, -7) != 0           # 3/-14/-7 is not compiled
+    # edit-distance scores under BitPAl run on the Myers kernels (the generator's isEdit case)
+    assert L.bgsa_hip_select_scores(0, -3, -3) == 0
+    assert L.bgsa_hip_kernel_name(B.ALGO_BITPAL, 5).startswith(b"myers_global_asm_kernel<5, 1>")
+    assert L.bgsa_hip_select_scores(0, -7, -2) != 0            # = 0/-4/-2 = 2 x (0/-2/-1): not the edit set, not compiled
     assert L.bgsa_hip_select_algorithm(B.ALGO_MYERS) == 0
 
 

@@ -106,3 +106,58 @@ def test_single_rank_needs_no_process_group(oracle):
     sa = ShardedAligner(dist=None, score_fn=lambda a, b: torch.from_numpy(oracle.myers64(a, b)))
     result, shards = sa.run(q, s)
     assert len(shards) == 1 and np.array_equal(result.numpy(), oracle.myers64(q, s))
+
+
+# ---- the streamed per-block gather (ScoreGatherStream): block i travels while block i+1 is scored ----------
+def _stream_worker(rank, world, port, layout, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, str(ROOT))
+    import oracle as O
+
+    q = O.gen_reads(21, 23, 150) if rank == 0 else None      # 23 queries in blocks of 5: a ragged last block
+    s = O.gen_reads(22, 333, 150)                            # 333 subjects: ragged last shard
+    sa = ShardedAligner(dist=dist, score_fn=lambda a, b: torch.from_numpy(O.myers64(a, b)))
+    blocks, shards = sa.run_streamed(q, s, block_rows=5, layout=layout)
+    if rank == 0:
+        np.save(out_path, np.concatenate([b.reshape(-1) for b in blocks]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,layout", [(2, "device_blocks"), (2, "row_major"), (3, "device_blocks")])
+def test_streamed_gather_under_gloo(tmp_path, oracle, world, layout):
+    out = tmp_path / "blocks.npy"
+    mp.spawn(_stream_worker, args=(world, _free_port(), layout, str(out)), nprocs=world, join=True)
+    got = np.load(out)
+    q = oracle.gen_reads(21, 23, 150)
+    s = oracle.gen_reads(22, 333, 150)
+    want = oracle.myers64(q, s)
+    shards = plan_shards(333, world)
+    parts = []
+    for lo in range(0, 23, 5):
+        blk = want[lo:lo + 5]
+        if layout == "row_major":
+            parts.append(blk.reshape(-1))
+        else:   # the reference's result order for one block: device 0's tile, then device 1's, ... (cal_mic.c:535-536)
+            parts += [blk[:, sh.start: sh.start + sh.count].reshape(-1) for sh in shards]
+    assert np.array_equal(got, np.concatenate(parts))
+
+
+def test_streamed_gather_single_rank_and_validation(oracle):
+    from bgsa_amd.multi_gpu import ScoreGatherStream
+    seen = []
+    gs = ScoreGatherStream(None, "cpu", [70], torch.int16, block_rows=4, on_block=lambda i, t: seen.append((i, t.clone())))
+    tiles = [torch.arange(4 * 70, dtype=torch.int16).reshape(4, 70) + b for b in range(5)]
+    for t in tiles[:4]:
+        gs.submit(t)
+    gs.submit(tiles[4][:3])                  # ragged last block
+    gs.drain()
+    assert [i for i, _ in seen] == [0, 1, 2, 3, 4]
+    for (i, got), t in zip(seen, tiles):
+        assert torch.equal(got.reshape(-1), (t if i < 4 else t[:3]).reshape(-1))
+    with pytest.raises(ValueError):
+        gs.submit(torch.zeros((5, 70), dtype=torch.int16))
+    with pytest.raises(ValueError):
+        ScoreGatherStream(None, "cpu", [70, 70], torch.int16, block_rows=4)
