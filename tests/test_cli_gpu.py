@@ -213,3 +213,47 @@ def test_reference_host_pipeline_other_scores(tmp_path, oracle):
     got, report = _run_reference_host(tmp_path, g, "aligner_bitpal", env_extra={"BGSA_HIP_SCORES": f"{m},{x},{gp}"})
     assert np.array_equal(got, oracle.dp_nw(q, s, m, x, gp))
     assert f"score is {m}, {x}, {gp}" in report
+
+
+# ---- the banded drop-in: banded/BGSA_CPU's OWN main.c (-k) / file.c / thread.c / cal_cpu.c — its word_num
+# formula (cal_cpu.c:253-254), its 64-bit cpu_read_t, its int8 results — compiled unmodified against the
+# library (oracle/Makefile: _ref/banded_hip, examples/BGSA_HIP/config_banded_hip.h) -------------------------
+BANDED_HIP = ROOT / "oracle" / "_ref" / "banded_hip" / "aligner"
+
+
+def _run_banded_host(tmp_path, g, k, threads=4):
+    (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
+    (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
+    cmd = [str(BANDED_HIP), "-q", "query.txt", "-d", "subject.txt", "-f", "result.txt", "-N", str(threads)]
+    if k is not None:
+        cmd += ["-k", str(k)]
+    p = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    conv = ROOT / "oracle" / "_ref" / "banded_cpu" / "convert"       # the reference's own int8 decoder
+    subprocess.run([str(conv), "-r", "result.txt", "-o", "scores.txt"], cwd=tmp_path, check=True, capture_output=True)
+    flat = np.loadtxt(tmp_path / "scores.txt", dtype=np.int64, ndmin=1)
+    return flat.reshape(g["queries"].shape[0], g["subjects"].shape[0]), p.stdout
+
+
+@pytest.mark.parametrize("name", ["f8_banded_k8_150", "f8_banded_k4_150", "f8_banded_k16_150", "f8_banded_k8_len500",
+                                  "f8_banded_k8_len73"])
+def test_banded_reference_host_pipeline_on_the_gpu_library(tmp_path, name):
+    if not BANDED_HIP.exists():
+        pytest.skip("oracle/_ref/banded_hip not built (needs /root/reference at build time)")
+    g = load_golden(name)
+    got, report = _run_banded_host(tmp_path, g, g["k"])
+    assert np.array_equal(got, g["scores"])          # the reference's scores, through its own banded host code
+    assert "GCUPS" in report
+
+
+def test_banded_reference_host_default_threshold(tmp_path, oracle):
+    # no -k: banded/BGSA_CPU/main.c:43 sets threshold = CPU_WORD_SIZE / 2 - 1 = 31 (the 64-bit band kernel);
+    # the reference's word_num for k = 31 is smaller than the device layout, so the seam re-pitches it
+    if not BANDED_HIP.exists():
+        pytest.skip("oracle/_ref/banded_hip not built")
+    q = oracle.gen_reads(171, 7, 150)
+    s = oracle.gen_reads(172, 200, 150)
+    s[:60] = oracle.mutate(q[np.arange(60) % 7], np.arange(60) % 40, 173)
+    got, _ = _run_banded_host(tmp_path, {"queries": q, "subjects": s}, None)
+    want = oracle.banded64(q, s, 31)
+    assert np.array_equal(got, want) and (want != 127).any() and (want == 127).any()

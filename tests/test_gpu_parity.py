@@ -308,6 +308,168 @@ def test_host_surface_matches_device_surface(oracle):
     assert np.array_equal(res[64:128], want[2, 64:128]) and not res[:64].any()
 
 
+def _host_seam_inputs(L, q, s):
+    table = np.ctypeslib.as_array((ctypes.c_uint32 * 128).in_dll(L, "mapping_table"))
+    sbuf = B.rows_to_buffer(s)
+    seq = B.SeqT(len=s.shape[1], size=sbuf.size, count=s.shape[0], extra_size=0, extra_count=0, content=sbuf.ctypes.data)
+    qbuf = B.rows_to_buffer(q)
+    keep = qbuf == ord("\n")
+    qmapped = table[qbuf].astype(np.uint8)
+    qmapped[keep] = ord("\n")
+    return sbuf, seq, qmapped
+
+
+@pytest.mark.parametrize("fixture,k,ref_word_num", [("f8_banded_k8_150", 8, False), ("f8_banded_k8_150", 8, True),
+                                                    ("f8_banded_k16_150", 16, True), ("f8_banded_k4_150", 4, False),
+                                                    (None, 31, False), (None, 31, True)])
+def test_host_surface_banded(oracle, fixture, k, ref_word_num):
+    """hip_handle_reads + hip_cal_align_score + align_hip for the banded filter: int8 results, the global
+    `threshold`, and both word_num conventions the seams accept — the library's own (32-bit words) and the
+    reference's banded formula over 64-bit words (banded/BGSA_CPU/cal_cpu.c:253-254)."""
+    L = B.lib()
+    if fixture:
+        g = load_golden(fixture)
+        q, s0, want0 = g["queries"], g["subjects"], g["scores"]
+    else:
+        q = oracle.gen_reads(51, 5, 150)
+        s0 = oracle.gen_reads(52, 130, 150)
+        s0[:50] = oracle.mutate(q[np.arange(50) % 5], np.arange(50) % 45, 53)
+        want0 = oracle.banded64(q, s0, k)
+    s, _ = B.pad_rows(s0)
+    n, length = s.shape
+    nq = q.shape[0]
+    want = np.full((nq, n), 0, dtype=np.int8)
+    want[:, : s0.shape[0]] = want0
+    want[:, s0.shape[0]:] = oracle.banded64(q, s[s0.shape[0]:], k) if n > s0.shape[0] else 0
+    L.bgsa_hip_select_algorithm(B.ALGO_BANDED)
+    threshold = ctypes.c_int.in_dll(L, "threshold")
+    old_threshold = threshold.value
+    threshold.value = k
+    try:
+        L.init_mapping_table()
+        sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+        if ref_word_num:
+            wn = (length - k + 63) // 64 + 1                       # words of the reference's uint64_t cpu_read_t
+            peq = np.zeros(5 * wn * 64 * (n // 64), dtype=np.uint64)
+            group_elems = 5 * wn * 64
+        else:
+            wn = B.word_num(B.ALGO_BANDED, length, length, k)
+            peq = np.zeros(B.group_words(B.ALGO_BANDED, wn, k) * (n // 64), dtype=np.uint32)
+            group_elems = B.group_words(B.ALGO_BANDED, wn, k)
+        L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+        out = np.zeros((nq, n), dtype=np.int8)
+        L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, length, nq, length, n, 0, nq, wn, 27, None)
+        assert np.array_equal(out, want)
+        out2 = np.zeros((2, n), dtype=np.int8)                      # a query window
+        L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out2.ctypes.data, length, nq, length, n, 1, 3, wn, 27, None)
+        assert np.array_equal(out2, want[1:3])
+        # fine-grained call: one query against the last group only, int8 results at result_index
+        res = np.zeros(n, dtype=np.int8)
+        row = np.ascontiguousarray(qmapped[2 * (length + 1): 3 * (length + 1)])
+        last = n // 64 - 1
+        grp = peq[last * group_elems:]
+        L.align_hip(row.ctypes.data, grp.ctypes.data, length, length, wn, 1, last, res.ctypes.data, None)
+        assert np.array_equal(res[last * 64:], want[2, last * 64:]) and not res[: last * 64].any()
+    finally:
+        threshold.value = old_threshold
+        L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+
+
+@pytest.mark.parametrize("fixture", ["f7_bitpal_150", "f9_bitpal_140x150", "f5_bitpal_specials"])
+def test_host_surface_bitpal(oracle, fixture):
+    """The same three seams with BGSA_ALGO_BITPAL selected (int16 results, the five score ints)."""
+    L = B.lib()
+    g = load_golden(fixture)
+    q, s0 = g["queries"], g["subjects"]
+    s, _ = B.pad_rows(s0)
+    n, length = s.shape
+    nq, qlen = q.shape
+    want = oracle.bitpal(q, s)
+    assert np.array_equal(want[:, : s0.shape[0]], g["scores"])
+    L.bgsa_hip_select_algorithm(B.ALGO_BITPAL)
+    try:
+        L.init_mapping_table()
+        sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+        wn = B.word_num(B.ALGO_BITPAL, qlen, length)
+        peq = np.zeros(B.group_words(B.ALGO_BITPAL, wn) * (n // 64), dtype=np.uint32)
+        L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+        out = np.zeros((nq, n), dtype=np.int16)
+        L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, qlen, nq, length, n, 0, nq, wn, 27, None)
+        assert np.array_equal(out, want)
+        res = np.zeros(n, dtype=np.int16)
+        row = np.ascontiguousarray(qmapped[0: qlen + 1])
+        L.align_hip(row.ctypes.data, peq.ctypes.data, qlen, length, wn, n // 64, 0, res.ctypes.data, None)
+        assert np.array_equal(res, want[0])
+    finally:
+        L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+
+
+def test_host_seam_keeps_the_bucket_resident(oracle):
+    """100-query blocks against one bucket: the Peq words cross PCIe once, not once per call; rewriting
+    the buffer with hip_handle_reads invalidates the device copy; auto-residency can be switched off."""
+    L = B.lib()
+    q = oracle.gen_reads(61, 12, 150)
+    s, _ = B.pad_rows(oracle.gen_reads(62, 256, 150))
+    s2, _ = B.pad_rows(oracle.gen_reads(63, 256, 150))
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.init_mapping_table()
+    sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+    wn = 5
+    peq = np.zeros(B.group_words(B.ALGO_MYERS, wn) * 4, dtype=np.uint32)
+
+    def uploads():
+        u = ctypes.c_uint64()
+        L.bgsa_hip_seam_stats(None, ctypes.byref(u), None)
+        return u.value
+
+    L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, 256)
+    before = uploads()
+    out = np.zeros((4, 256), dtype=np.int16)
+    for lo in (0, 4, 8):
+        L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, 150, 12, 150, 256, lo, lo + 4, wn, 27, None)
+        assert np.array_equal(out, oracle.myers64(q[lo:lo + 4], s))
+    assert uploads() == before + 1                       # three calls, one upload
+    # a sub-range of the resident bucket (what align_hip passes) uses the same copy
+    res = np.zeros(256, dtype=np.int16)
+    L.align_hip(qmapped[:151].copy().ctypes.data, peq[B.group_words(B.ALGO_MYERS, wn) * 2:].ctypes.data, 150, 150, wn, 2, 2,
+                res.ctypes.data, None)
+    assert np.array_equal(res[128:], oracle.myers64(q[:1], s)[0, 128:]) and uploads() == before + 1
+    # new content in the same host buffer: hip_handle_reads drops the stale copy
+    sbuf2, seq2, _ = _host_seam_inputs(L, q, s2)
+    peq[:] = 0
+    L.hip_handle_reads(ctypes.byref(seq2), peq.ctypes.data, wn, 0, 256)
+    L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, 150, 12, 150, 256, 0, 4, wn, 27, None)
+    assert np.array_equal(out, oracle.myers64(q[:4], s2)) and uploads() == before + 2
+    # stateless mode: every call uploads
+    assert L.bgsa_hip_set_auto_resident(0) == 0
+    try:
+        peq[:] = 0
+        L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, 256)
+        n0 = uploads()
+        for _ in range(2):
+            L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, 150, 12, 150, 256, 0, 4, wn, 27, None)
+            assert np.array_equal(out, oracle.myers64(q[:4], s))
+        assert uploads() == n0 + 2
+    finally:
+        L.bgsa_hip_set_auto_resident(1)
+        L.bgsa_hip_bucket_release(None)
+
+
+def test_wrong_word_num_is_refused(oracle):
+    # the kernels index the blocks with the caller's word_num: anything but the layout's own value is an error
+    import torch
+    L = B.lib()
+    a = B.DeviceAligner(B.ALGO_BANDED, k=8)
+    a.set_queries(oracle.gen_reads(1, 2, 150))
+    a.set_subjects(oracle.gen_reads(2, 64, 150))
+    out = torch.empty((2, 64), dtype=torch.int8, device="cuda:0")
+    p = a.params()
+    for bad in (a.wn - 1, a.wn + 1, 4):     # 4 = the reference's banded value for 150 bp, k = 8 (host seams only)
+        rc = L.bgsa_hip_cal_align_score_ex(ctypes.byref(p), a.d_content.data_ptr(), a.d_peq.data_ptr(), out.data_ptr(),
+                                           150, 150, 64, 0, 2, bad, None, 0, None)
+        assert rc == -1 and b"word_num" in L.bgsa_hip_last_error()
+
+
 # ---- BitPAl with other integer scores (SURVEY 8(f) row f3): every compiled set against the
 # Needleman-Wunsch oracle; the reference commits generator output for 2/-3/-5 only, so for the other
 # sets the DP definition is the checker -------------------------------------------------------------
@@ -328,6 +490,26 @@ def test_bitpal_score_sets_vs_needleman_wunsch(oracle, scores, qlen, slen):
     s = _related(oracle, q, 130, slen, 200 + slen)
     got = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=scores)
     assert np.array_equal(got, oracle.dp_nw(q, s, *scores))
+
+
+@pytest.mark.parametrize("scores", [(0, -1, -1), (0, -3, -3), (1, -9, -2), (2, -9, -4), (1, -4, -2)])
+@pytest.mark.parametrize("qlen,slen", [(150, 150), (60, 300), (97, 1500)])
+def test_normalised_score_sets_vs_needleman_wunsch(oracle, scores, qlen, slen):
+    """Edit-distance sets (0,-f,-f) run on the Myers body x f; a mismatch below two gaps runs as its
+    mismatch = 2*gap instance (1/-9/-2 = 1/-4/-2).  Checker: the textbook DP with the scores as given."""
+    if scores[0] != 0 and (1, -4, -2) not in B.score_sets():
+        pytest.skip("1/-4/-2 not compiled in")
+    q = oracle.gen_reads(100 + qlen, 5, qlen)
+    s = _related(oracle, q, 130, slen, 200 + slen)
+    got = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=scores)
+    assert np.array_equal(got, oracle.dp_nw(q, s, *scores))
+    if scores[0] == 0:
+        a = B.DeviceAligner(B.ALGO_BITPAL, scores=scores)
+        a.set_queries(q)
+        a.set_subjects(s)
+        a._select()
+        assert "myers" in B.lib().bgsa_hip_kernel_name(B.ALGO_BITPAL, a.wn).decode()
+        B.lib().bgsa_hip_select_algorithm(B.ALGO_MYERS)
 
 
 def test_bitpal_edit_scores_agree_with_the_myers_kernel(oracle):
@@ -388,12 +570,17 @@ def test_semiglobal_is_refused_for_other_algorithms_and_does_not_stick(oracle):
     L = B.lib()
     assert L.bgsa_hip_select_alignment(1) == 0
     try:
-        with pytest.raises(B.BgsaHipError, match="semi-global"):
-            a = B.DeviceAligner(B.ALGO_BANDED, k=8)
-            a._select = lambda: None          # bypass the wrapper's own mode reset: the C ABI must refuse
-            a.set_queries(q)
-            a.set_subjects(s)
-            a.score()
+        # the entry point that reads the process-global mode must refuse banded while it says semi-global
+        import torch
+        a = B.DeviceAligner(B.ALGO_BANDED, k=8)
+        a.set_queries(q)
+        a.set_subjects(s)
+        out = torch.empty((3, 64), dtype=torch.int8, device="cuda:0")
+        rc = L.bgsa_hip_cal_align_score_dev(B.ALGO_BANDED, a.d_content.data_ptr(), a.d_peq.data_ptr(), out.data_ptr(),
+                                            80, 80, 64, 0, 3, a.wn, 8, None, 0, None)
+        assert rc == -2 and b"semi-global" in L.bgsa_hip_last_error()
+        # ... while an aligner that passes its own parameters is not affected by the global at all
+        assert np.array_equal(a.score().cpu().numpy(), oracle.banded64(q, s, 8))
     finally:
         assert L.bgsa_hip_select_alignment(0) == 0
 
