@@ -169,7 +169,8 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void banded_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
-    unsigned *__restrict__ fault_word)
+    unsigned *__restrict__ fault_word, int q_base, uint32_t push_row, uint32_t push_max,
+    uint2 *__restrict__ queue, unsigned *__restrict__ queue_count)
 {
     constexpr int NM = WIDE ? 4 : 3;  // resident 32-bit words per class, the last one is the prefetch target
     const int lane = threadIdx.x & (kLanes - 1);
@@ -209,21 +210,36 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
         unsigned long long dead_mask;
         unsigned long long vp, vn;
         uint32_t acc;
-        int left;
+        int left, early;
         if constexpr (WIDE) {
             dead_mask = banded_rows_asm64(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band),
-                                          static_cast<uint32_t>(band >> 32), limit, left);
+                                          static_cast<uint32_t>(band >> 32), limit, push_row, push_max, left, early);
             vp = st[0] | (static_cast<unsigned long long>(st[1]) << 32);
             vn = st[2] | (static_cast<unsigned long long>(st[3]) << 32);
             acc = st[4];
         } else {
-            dead_mask = banded_rows_asm32(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band), 0u, limit, left);
+            dead_mask = banded_rows_asm32(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band), 0u, limit,
+                                          push_row, push_max, left, early);
             vp = st[0];
             vn = st[1];
             acc = st[2];
         }
         note_stream_fault(fault_word, left);
         const bool dead = (dead_mask >> lane) & 1ull;
+        if (early) {
+            // Survivor queue: the wave stopped at a test that found only a few lanes within the limit.  Those
+            // pairs are finished by banded_pairs_kernel, one pair per lane, from row 0; the others are rejected.
+            const unsigned long long alive = ~dead_mask;
+            unsigned slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(queue_count, static_cast<unsigned>(__popcll(alive)));
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            if (dead)
+                dst[static_cast<size_t>(q) * ld] = static_cast<int8_t>(HIP_MAX_ERROR);
+            else
+                queue[slot0 + __popcll(alive & ((1ull << lane) - 1ull))] =
+                    make_uint2(static_cast<unsigned>(q_base + q), static_cast<unsigned>(group) * kLanes + lane);
+            continue;
+        }
         int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
         if (dead_mask != ~0ull) {
             // :230-245 — walk the last row across the band, keep the minimum.
@@ -239,7 +255,106 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
     }
 }
 
+// ---- survivor queue, second pass ---------------------------------------------------------------------
+// The filter exists to reject: on realistic inputs a wave of 64 subjects holds at most a few pairs that
+// survive, and running all 64 lanes to the last row for them is what makes sparse survivors expensive
+// (1 % of the pairs surviving, scattered: 47 % of the waves ran to the end, 2.6x the time of random pairs).
+// So a wave that finds 1..push_max lanes alive at a late test stops and queues them as (query, subject)
+// pairs; this kernel then scores the queued pairs one per lane, densely, from row 0 — the same recurrence,
+// tests and final walk as banded_kernel<T>, with the query character and the match words selected per
+// lane (the pairs of a wave have nothing in common).  Whatever gets here is scored exactly, so where the
+// first pass stops is a pure performance choice.
+template <typename T>
+__global__ __launch_bounds__(256) void banded_pairs_kernel(
+    const char *__restrict__ content, const uint32_t *__restrict__ mext, int8_t *__restrict__ out, int len,
+    long long ld, int word_num, int ref_start, int k, const uint2 *__restrict__ queue,
+    const unsigned *__restrict__ queue_count)
+{
+    constexpr int W = BandWord<T>::bits;
+    const unsigned n = *queue_count;
+    const int h = k;
+    const int band_down = k + h;
+    const T band_mask = (band_down + 1 >= W) ? ~T(0) : ((T(1) << (band_down + 1)) - 1);
+    const uint32_t max_err = static_cast<uint32_t>(k + h + 1);
+    const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 pair = queue[i];
+        const int q = static_cast<int>(pair.x);                  // index within [ref_start, ref_end)
+        const unsigned subject = pair.y;
+        const uint32_t *g = mext + static_cast<size_t>(subject >> 6) * kChars * word_num * kLanes + (subject & 63u);
+        const unsigned char *qrow = reinterpret_cast<const unsigned char *>(content) + static_cast<size_t>(ref_start + q) * (len + 1);
+        T vp = 0, vn = 0;
+        uint32_t acc = 0;
+        bool dead = false;
+        uint32_t x0[kChars], x1[kChars], x2[kChars];
+#pragma unroll
+        for (int c = 0; c < kChars; c++) {
+            x0[c] = 0u;
+            x1[c] = g[(c * word_num + 0) * kLanes];
+            x2[c] = word_num > 1 ? g[(c * word_num + 1) * kLanes] : 0u;
+        }
+        for (int r0 = 0; r0 < len; r0 += 32) {
+            const int wi = r0 >> 5;
+#pragma unroll
+            for (int c = 0; c < kChars; c++) {
+                x0[c] = x1[c];
+                x1[c] = x2[c];
+                x2[c] = (wi + 2 < word_num) ? g[(c * word_num + wi + 2) * kLanes] : 0u;
+            }
+            const int rows = len - r0 < 32 ? len - r0 : 32;
+            for (int j = 0; j < rows; j++) {
+                const int r = r0 + j;
+                uint32_t c = qrow[r];
+                c = c > 4u ? 0u : c;
+                const uint32_t a = c == 0 ? x0[0] : c == 1 ? x0[1] : c == 2 ? x0[2] : c == 3 ? x0[3] : x0[4];
+                const uint32_t b = c == 0 ? x1[0] : c == 1 ? x1[1] : c == 2 ? x1[2] : c == 3 ? x1[3] : x1[4];
+                T win = BandWord<uint32_t>::funnel(b, a, j);
+                if constexpr (W == 64) {
+                    const uint32_t d = c == 0 ? x2[0] : c == 1 ? x2[1] : c == 2 ? x2[2] : c == 3 ? x2[3] : x2[4];
+                    win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
+                }
+                if (r == k) acc = 0;
+                band_row<T>(win & band_mask, vp, vn, acc);
+                if (r + 1 == last_check) dead = static_cast<uint32_t>(k) + acc > max_err;
+            }
+        }
+        int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+        if (!dead) {
+            uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
+            for (int i2 = 0; i2 <= h; i2++) {
+                err += static_cast<uint32_t>((vp >> i2) & 1);
+                err -= static_cast<uint32_t>((vn >> i2) & 1);
+                best = err < best ? err : best;
+            }
+            result = static_cast<int8_t>(best);
+        }
+        out[static_cast<size_t>(q) * ld + subject] = result;
+    }
+}
+
 namespace {
+
+// Survivor-queue policy (measurement knobs; any value gives the same scores): a wave hands its survivors
+// to the queue when a test at or after row k + BGSA_BANDED_PUSH_ROW (default 40) finds at most
+// BGSA_BANDED_PUSH_MAX (default 4, 0 = never) lanes within the limit.
+int banded_push_max()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_BANDED_PUSH_MAX");
+        const int x = e ? atoi(e) : 4;
+        return (x >= 0 && x <= 64) ? x : 4;
+    }();
+    return v;
+}
+int banded_push_row_offset()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_BANDED_PUSH_ROW");
+        const int x = e ? atoi(e) : 40;
+        return x >= 0 ? x : 40;
+    }();
+    return v;
+}
 
 int banded_impl()
 {
@@ -257,25 +372,54 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     const int64_t n_groups = read_count / kLanes;
     int q_tile = 32;
     while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
-    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
-              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
-    if (grid.y > 65535u) {
-        set_error_text("banded: too many query tiles for one launch");
-        return BGSA_HIP_EUNSUPPORTED;
-    }
     if (int rc = launch_pack_banded(d_content, len, k, ref_start, ref_end, d_workspace, stream)) return rc;
     const int stride = banded_stream_layout(len, k, nullptr, nullptr);
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kBandedRefill, 40, stream, &fault)) return rc;
-    if (k <= 15)
-        hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream,
-                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
-                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride, fault);
-    else
-        hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream,
-                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
-                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride, fault);
-    BGSA_HIP_TRY(hipGetLastError());
+
+    // Workspace: [streams: banded_stream_bound(len) * nq][queue counter: 256 B][queue: kBandedQueueBytes].
+    // A (wave, query) queues at most push_max pairs, so a slice of queries whose waves cannot overflow the
+    // queue is scored per pass: first pass, then the queued pairs, then the next slice.
+    unsigned char *ws = static_cast<unsigned char *>(d_workspace);
+    unsigned *queue_count = reinterpret_cast<unsigned *>(ws + banded_stream_bound(len) * static_cast<size_t>(nq));
+    uint2 *queue = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(queue_count) + 256);
+    int push_max = banded_push_max();
+    const int64_t capacity = static_cast<int64_t>(kBandedQueueBytes / sizeof(uint2));
+    int64_t slice = push_max > 0 ? capacity / (n_groups * push_max) : nq;
+    if (slice < q_tile) { push_max = 0; slice = nq; }   // a bucket too large for the queue: no compaction
+    slice = slice / q_tile * q_tile;
+    if (slice > nq) slice = nq;
+    const uint32_t push_row = static_cast<uint32_t>(k + banded_push_row_offset());
+    for (int q0 = 0; q0 < nq; q0 += static_cast<int>(slice)) {
+        const int nqs = static_cast<int>(q0 + slice <= nq ? slice : nq - q0);
+        dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+                  static_cast<unsigned>((nqs + q_tile - 1) / q_tile));
+        if (grid.y > 65535u) {
+            set_error_text("banded: too many query tiles for one launch");
+            return BGSA_HIP_EUNSUPPORTED;
+        }
+        if (push_max > 0) BGSA_HIP_TRY(hipMemsetAsync(queue_count, 0, sizeof(unsigned), stream));
+        const unsigned char *streams = ws + static_cast<size_t>(q0) * stride;
+        int8_t *out = d_results + static_cast<size_t>(q0) * read_count;
+        if (k <= 15)
+            hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream, streams, d_peq, out,
+                               static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nqs, q_tile, k, stride,
+                               fault, q0, push_row, static_cast<uint32_t>(push_max), queue, queue_count);
+        else
+            hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream, streams, d_peq, out,
+                               static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nqs, q_tile, k, stride,
+                               fault, q0, push_row, static_cast<uint32_t>(push_max), queue, queue_count);
+        BGSA_HIP_TRY(hipGetLastError());
+        if (push_max > 0) {
+            if (k <= 15)
+                hipLaunchKernelGGL(banded_pairs_kernel<uint32_t>, dim3(kBandedPairGrid), dim3(256), 0, stream, d_content, d_peq,
+                                   d_results, len, static_cast<long long>(read_count), word_num, ref_start, k, queue, queue_count);
+            else
+                hipLaunchKernelGGL(banded_pairs_kernel<uint64_t>, dim3(kBandedPairGrid), dim3(256), 0, stream, d_content, d_peq,
+                                   d_results, len, static_cast<long long>(read_count), word_num, ref_start, k, queue, queue_count);
+            BGSA_HIP_TRY(hipGetLastError());
+        }
+    }
     return BGSA_HIP_OK;
 }
 

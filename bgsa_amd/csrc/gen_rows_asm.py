@@ -274,7 +274,10 @@ def gen_banded_function(wide: bool) -> str:
     S_MASK, S_SH, S_ARG, S_THR, S_MASK_HI = "s72", "s73", "s74", "s78", "s75"
     S_DEAD, S_TMP = "s[76:77]", "s[90:91]"
     S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
-    clobbers = CLOBBERS[:-3] + ["s72", "s73", "s74", "s75", "s76", "s77", "s78"] + [f"s{i}" for i in range(80, 92)] + \
+    # survivor compaction (banded.hip "survivor queue"): rows done = 32 * S_CHUNK + S_SH; a test at or after row
+    # S_PUSHROW that finds 1..S_PUSHMAX lanes alive ends the wave with S_EARLY = 1, the alive lanes go to the queue
+    S_CHUNK, S_PUSHROW, S_PUSHMAX, S_EARLY, S_CNT = "s92", "s93", "s94", "s95", "s79"
+    clobbers = CLOBBERS[:-3] + ["s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"] + [f"s{i}" for i in range(80, 96)] + \
         ["vcc", "scc", "memory"]
 
     def reg_for(c: int):
@@ -319,6 +322,10 @@ def gen_banded_function(wide: bool) -> str:
         f"s_mov_b32 {S_THR}, %[thr]",
         f"s_mov_b32 {S_SH}, 0",
         f"s_mov_b64 {S_DEAD}, 0",
+        f"s_mov_b32 {S_CHUNK}, 0",
+        f"s_mov_b32 {S_EARLY}, 0",
+        f"s_mov_b32 {S_PUSHROW}, %[pushrow]",
+        f"s_mov_b32 {S_PUSHMAX}, %[pushmax]",
     ]
     asm += [f"s_mov_b64 {S_BASE[c]}, %[base{c}]" for c in range(5)]
     asm += [
@@ -378,9 +385,21 @@ def gen_banded_function(wide: bool) -> str:
         "s_cbranch_scc0 L_ev_all_%=",
         f"s_mov_b64 {S_DEAD}, vcc",
         "L_ev_all_%=:",
-        f"s_xor_b64 {S_TMP}, vcc, exec",
-        "s_cbranch_scc1 L_ev_reset_%=",
+        f"s_andn2_b64 {S_TMP}, exec, vcc",  # lanes still within the limit
+        "s_cbranch_scc1 L_ev_some_%=",
         f"s_mov_b64 {S_DEAD}, exec",       # every lane is past the limit: the wave is done
+        "s_branch L_done_%=",
+        "L_ev_some_%=:",
+        # few survivors late enough: hand them to the pair queue instead of running 64 lanes for them
+        f"s_lshl_b32 {S_CNT}, {S_CHUNK}, 5",
+        f"s_add_u32 {S_CNT}, {S_CNT}, {S_SH}",
+        f"s_cmp_ge_u32 {S_CNT}, {S_PUSHROW}",
+        "s_cbranch_scc0 L_ev_reset_%=",
+        f"s_bcnt1_i32_b64 {S_CNT}, {S_TMP}",
+        f"s_cmp_le_u32 {S_CNT}, {S_PUSHMAX}",
+        "s_cbranch_scc0 L_ev_reset_%=",
+        f"s_mov_b64 {S_DEAD}, vcc",
+        f"s_mov_b32 {S_EARLY}, 1",
         "s_branch L_done_%=",
         "L_ev_reset_%=:",
         f"s_bitcmp1_b32 {S_ARG}, 0",      # bit 0: scoring starts (row k)
@@ -398,19 +417,21 @@ def gen_banded_function(wide: bool) -> str:
     asm += [
         "v_add_u32 %[voff], 0x100, %[voff]",
         f"s_mov_b32 {S_SH}, 0",
+        f"s_add_u32 {S_CHUNK}, {S_CHUNK}, 1",
         "L_ev_out_%=:",
     ]
     asm += disp()
     asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")
     asm.append(f"s_mov_b64 %[dead], {S_DEAD}")
+    asm.append(f"s_mov_b32 %[early], {S_EARLY}")
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
     outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(n_m)]
-    outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)', '[left] "=s"(left)']
+    outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)', '[left] "=s"(left)', '[early] "=s"(early)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
     ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[mask] "s"(band_mask)', '[mask_hi] "s"(band_mask_hi)',
-           '[thr] "s"(limit)']
+           '[thr] "s"(limit)', '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
     clob = ", ".join(f'"{x}"' for x in clobbers)
     return f"""
@@ -420,11 +441,14 @@ def gen_banded_function(wide: bool) -> str:
 // offset of the next word to fetch relative to base[c]; returns the reject mask (lanes whose error
 // count passed `limit` at the last checkpoint, or all lanes if the wave stopped early).  left = the
 // stream's remaining window budget, negative after a malformed stream (gen_rows_asm.py: S_LEFT).
+// early = 1: a test at or after row push_row found 1..push_max lanes within the limit and the wave stopped
+// there; the returned mask then holds the lanes past the limit, the others go to the survivor queue.
 __device__ __forceinline__ unsigned long long banded_rows_asm{64 if wide else 32}(uint32_t (&state)[{n_state}], uint32_t (&M)[5][{n_m}], uint32_t &voff,
                                                               const unsigned long long (&base)[5],
                                                               const unsigned long long stream, const int n_windows,
                                                               const uint32_t band_mask, const uint32_t band_mask_hi,
-                                                              const uint32_t limit, int &left)
+                                                              const uint32_t limit, const uint32_t push_row,
+                                                              const uint32_t push_max, int &left, int &early)
 {{
     uint32_t tmp[{max(n_slots, 1)}];
     unsigned long long dead;

@@ -81,6 +81,27 @@ def test_banded_vs_oracle(oracle, length, k):
     assert (want != 127).any() and (want == 127).any()
 
 
+@pytest.mark.parametrize("k,length", [(8, 150), (20, 150), (8, 500), (12, 97)])
+def test_banded_sparse_survivors_take_the_queue(oracle, k, length):
+    """One or two near-duplicates per wave of 64 subjects among random reads: the first pass stops those waves
+    at a late test and the survivor queue's second pass scores the pairs (banded.hip).  Dense survivors
+    (a whole wave of near-duplicates) stay in the first pass.  Both against the oracle."""
+    rng = np.random.default_rng(k * 1000 + length)
+    q = oracle.gen_reads(7000 + k, 40, length)
+    s = oracle.gen_reads(7100 + length, 64 * 12, length)
+    for g in range(12):                                   # groups 0..9: 1-3 survivors each, at random lanes
+        if g < 10:
+            lanes = rng.choice(64, size=1 + g % 3, replace=False)
+        else:                                             # groups 10, 11: every lane a near-duplicate of some query
+            lanes = np.arange(64)
+        src = rng.integers(0, 40, len(lanes))
+        s[g * 64 + lanes] = oracle.mutate(q[src], rng.integers(0, k + 3, len(lanes)), 7200 + g)
+    got = B.align_all_pairs(q, s, algo=B.ALGO_BANDED, k=k)
+    want = oracle.banded64(q, s, k)
+    assert np.array_equal(got, want)
+    assert (want != 127).sum() >= 20
+
+
 def test_banded_refuses_unequal_lengths(oracle):
     with pytest.raises(B.BgsaHipError):
         B.align_all_pairs(oracle.gen_reads(1, 2, 140), oracle.gen_reads(2, 64, 150), algo=B.ALGO_BANDED, k=8)
@@ -742,6 +763,8 @@ print("knobs ok")
 
 
 @pytest.mark.parametrize("env", [{"BGSA_MYERS_IMPL": "c", "BGSA_BITPAL_IMPL": "c", "BGSA_BANDED_IMPL": "c"},
+                                 {"BGSA_BANDED_PUSH_MAX": "0"},                               # no survivor queue
+                                 {"BGSA_BANDED_PUSH_MAX": "64", "BGSA_BANDED_PUSH_ROW": "0"},   # everything alive at the first test is queued
                                  {"BGSA_MYERS_MAX_PLAIN_WORDS": "8"},
                                  {"BGSA_MYERS_MAX_PLAIN_WORDS": "8", "BGSA_MYERS_BLOCK_FORM": "planes"},
                                  {"BGSA_MYERS_PEQ_MAX_WORDS": "8"},
