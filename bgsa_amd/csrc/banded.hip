@@ -25,6 +25,8 @@
 // SURVEY.md §8(a) A5) — anything else is refused loudly.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "bgsa_common.h"
 
 namespace bgsa {
@@ -169,9 +171,13 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void banded_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
-    unsigned *__restrict__ fault_word, int q_base, uint32_t push_row, uint32_t push_max,
-    uint2 *__restrict__ queue, unsigned *__restrict__ queue_count)
+    unsigned *__restrict__ fault_word, const char *__restrict__ content, int ref_start, int len,
+    uint32_t push_row, uint32_t push_max)
 {
+    // survivors of this wave's query tile waiting for their dense pass: (query - q0) << 8 | lane
+    __shared__ uint32_t s_regroup[kWavesPerBlock][kLanes];
+    uint32_t *regroup = s_regroup[threadIdx.x >> 6];
+    int n_regroup = 0;   // wave-uniform
     constexpr int NM = WIDE ? 4 : 3;  // resident 32-bit words per class, the last one is the prefetch target
     const int lane = threadIdx.x & (kLanes - 1);
     const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
@@ -194,7 +200,77 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
     const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
     int8_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
 
-    for (int q = q0; q < q1; q++) {
+    for (int q = q0; q <= q1; q++) {
+        // Regrouping (one call site: the iteration q == q1 only flushes).  When the list could overflow, or the
+        // tile is done, the waiting pairs are scored one per lane, densely, from row 0: same recurrence, tests
+        // and final walk as banded_kernel<T>, with the query character selected per lane.  The lanes of this pass
+        // are pairs of THIS wave's group and THIS tile's queries, so every load below stays inside the group's
+        // Mext block and the tile's consecutive query rows.
+        if (n_regroup > kLanes - static_cast<int>(push_max) || (q == q1 && n_regroup > 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n_regroup) {
+                using T = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
+                const uint32_t entry = regroup[lane];
+                const int ql = static_cast<int>(entry >> 8);
+                const uint32_t sl = entry & 63u;
+                const uint32_t *gl = g + sl;
+                const unsigned char *qrow = reinterpret_cast<const unsigned char *>(content) +
+                                            static_cast<size_t>(ref_start + q0 + ql) * (len + 1);
+                const T band_mask = static_cast<T>(band);
+                const uint32_t max_err = static_cast<uint32_t>(k + h + 1);
+                const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
+                T vp = 0, vn = 0;
+                uint32_t acc = 0;
+                bool dead = false;
+                uint32_t x0[kChars], x1[kChars], x2[kChars];
+#pragma unroll
+                for (int c = 0; c < kChars; c++) {
+                    x0[c] = 0u;
+                    x1[c] = gl[(c * word_num + 0) * kLanes];
+                    x2[c] = gl[(c * word_num + 1) * kLanes];
+                }
+                for (int r0 = 0; r0 < len; r0 += 32) {
+                    const int wi = r0 >> 5;
+#pragma unroll
+                    for (int c = 0; c < kChars; c++) {
+                        x0[c] = x1[c];
+                        x1[c] = x2[c];
+                        x2[c] = (wi + 2 < word_num) ? gl[(c * word_num + wi + 2) * kLanes] : 0u;
+                    }
+                    const int rows = len - r0 < 32 ? len - r0 : 32;
+                    for (int j = 0; j < rows; j++) {
+                        const int r = r0 + j;
+                        uint32_t c = qrow[r];
+                        c = c > 4u ? 0u : c;
+                        const uint32_t a = c == 0 ? x0[0] : c == 1 ? x0[1] : c == 2 ? x0[2] : c == 3 ? x0[3] : x0[4];
+                        const uint32_t b = c == 0 ? x1[0] : c == 1 ? x1[1] : c == 2 ? x1[2] : c == 3 ? x1[3] : x1[4];
+                        T win = BandWord<uint32_t>::funnel(b, a, j);
+                        if constexpr (WIDE) {
+                            const uint32_t d = c == 0 ? x2[0] : c == 1 ? x2[1] : c == 2 ? x2[2] : c == 3 ? x2[3] : x2[4];
+                            win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
+                        }
+                        if (r == k) acc = 0;
+                        band_row<T>(win & band_mask, vp, vn, acc);
+                        if (r + 1 == last_check) dead = static_cast<uint32_t>(k) + acc > max_err;
+                    }
+                }
+                int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+                if (!dead) {
+                    uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
+                    for (int i = 0; i <= h; i++) {
+                        err += static_cast<uint32_t>((vp >> i) & 1);
+                        err -= static_cast<uint32_t>((vn >> i) & 1);
+                        best = err < best ? err : best;
+                    }
+                    result = static_cast<int8_t>(best);
+                }
+                out[static_cast<size_t>(q0 + ql) * ld + static_cast<size_t>(group) * kLanes + sl] = result;
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_regroup = 0;
+        }
+        if (q == q1) break;
         uint32_t st[WIDE ? 5 : 3];
 #pragma unroll
         for (int i = 0; i < (WIDE ? 5 : 3); i++) st[i] = 0u;
@@ -227,17 +303,14 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
         note_stream_fault(fault_word, left);
         const bool dead = (dead_mask >> lane) & 1ull;
         if (early) {
-            // Survivor queue: the wave stopped at a test that found only a few lanes within the limit.  Those
-            // pairs are finished by banded_pairs_kernel, one pair per lane, from row 0; the others are rejected.
+            // The wave stopped at a late test that found only a few lanes within the limit: those pairs wait in
+            // the regroup list for the dense pass above; the other lanes are rejected here.
             const unsigned long long alive = ~dead_mask;
-            unsigned slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd(queue_count, static_cast<unsigned>(__popcll(alive)));
-            slot0 = __builtin_amdgcn_readfirstlane(slot0);
             if (dead)
                 dst[static_cast<size_t>(q) * ld] = static_cast<int8_t>(HIP_MAX_ERROR);
             else
-                queue[slot0 + __popcll(alive & ((1ull << lane) - 1ull))] =
-                    make_uint2(static_cast<unsigned>(q_base + q), static_cast<unsigned>(group) * kLanes + lane);
+                regroup[n_regroup + __popcll(alive & ((1ull << lane) - 1ull))] = (static_cast<uint32_t>(q - q0) << 8) | lane;
+            n_regroup += __builtin_amdgcn_readfirstlane(static_cast<int>(__popcll(alive)));
             continue;
         }
         int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
@@ -255,94 +328,25 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
     }
 }
 
-// ---- survivor queue, second pass ---------------------------------------------------------------------
+// ---- regrouping of sparse survivors -------------------------------------------------------------------
 // The filter exists to reject: on realistic inputs a wave of 64 subjects holds at most a few pairs that
-// survive, and running all 64 lanes to the last row for them is what makes sparse survivors expensive
-// (1 % of the pairs surviving, scattered: 47 % of the waves ran to the end, 2.6x the time of random pairs).
-// So a wave that finds 1..push_max lanes alive at a late test stops and queues them as (query, subject)
-// pairs; this kernel then scores the queued pairs one per lane, densely, from row 0 — the same recurrence,
-// tests and final walk as banded_kernel<T>, with the query character and the match words selected per
-// lane (the pairs of a wave have nothing in common).  Whatever gets here is scored exactly, so where the
-// first pass stops is a pure performance choice.
-template <typename T>
-__global__ __launch_bounds__(256) void banded_pairs_kernel(
-    const char *__restrict__ content, const uint32_t *__restrict__ mext, int8_t *__restrict__ out, int len,
-    long long ld, int word_num, int ref_start, int k, const uint2 *__restrict__ queue,
-    const unsigned *__restrict__ queue_count)
-{
-    constexpr int W = BandWord<T>::bits;
-    const unsigned n = *queue_count;
-    const int h = k;
-    const int band_down = k + h;
-    const T band_mask = (band_down + 1 >= W) ? ~T(0) : ((T(1) << (band_down + 1)) - 1);
-    const uint32_t max_err = static_cast<uint32_t>(k + h + 1);
-    const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint2 pair = queue[i];
-        const int q = static_cast<int>(pair.x);                  // index within [ref_start, ref_end)
-        const unsigned subject = pair.y;
-        const uint32_t *g = mext + static_cast<size_t>(subject >> 6) * kChars * word_num * kLanes + (subject & 63u);
-        const unsigned char *qrow = reinterpret_cast<const unsigned char *>(content) + static_cast<size_t>(ref_start + q) * (len + 1);
-        T vp = 0, vn = 0;
-        uint32_t acc = 0;
-        bool dead = false;
-        uint32_t x0[kChars], x1[kChars], x2[kChars];
-#pragma unroll
-        for (int c = 0; c < kChars; c++) {
-            x0[c] = 0u;
-            x1[c] = g[(c * word_num + 0) * kLanes];
-            x2[c] = word_num > 1 ? g[(c * word_num + 1) * kLanes] : 0u;
-        }
-        for (int r0 = 0; r0 < len; r0 += 32) {
-            const int wi = r0 >> 5;
-#pragma unroll
-            for (int c = 0; c < kChars; c++) {
-                x0[c] = x1[c];
-                x1[c] = x2[c];
-                x2[c] = (wi + 2 < word_num) ? g[(c * word_num + wi + 2) * kLanes] : 0u;
-            }
-            const int rows = len - r0 < 32 ? len - r0 : 32;
-            for (int j = 0; j < rows; j++) {
-                const int r = r0 + j;
-                uint32_t c = qrow[r];
-                c = c > 4u ? 0u : c;
-                const uint32_t a = c == 0 ? x0[0] : c == 1 ? x0[1] : c == 2 ? x0[2] : c == 3 ? x0[3] : x0[4];
-                const uint32_t b = c == 0 ? x1[0] : c == 1 ? x1[1] : c == 2 ? x1[2] : c == 3 ? x1[3] : x1[4];
-                T win = BandWord<uint32_t>::funnel(b, a, j);
-                if constexpr (W == 64) {
-                    const uint32_t d = c == 0 ? x2[0] : c == 1 ? x2[1] : c == 2 ? x2[2] : c == 3 ? x2[3] : x2[4];
-                    win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
-                }
-                if (r == k) acc = 0;
-                band_row<T>(win & band_mask, vp, vn, acc);
-                if (r + 1 == last_check) dead = static_cast<uint32_t>(k) + acc > max_err;
-            }
-        }
-        int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
-        if (!dead) {
-            uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
-            for (int i2 = 0; i2 <= h; i2++) {
-                err += static_cast<uint32_t>((vp >> i2) & 1);
-                err -= static_cast<uint32_t>((vn >> i2) & 1);
-                best = err < best ? err : best;
-            }
-            result = static_cast<int8_t>(best);
-        }
-        out[static_cast<size_t>(q) * ld + subject] = result;
-    }
-}
-
+// survive, and running all 64 lanes to the last row for them is what made sparse survivors expensive
+// (1 % of the pairs surviving, scattered over the subjects: 47 % of the waves ran to the end — 2.6x the time
+// of random pairs).  A wave that finds 1..push_max lanes alive at a late test therefore stops and puts them
+// on a list (LDS, per wave); when the list is nearly full or the wave's query tile is done, the listed pairs
+// are scored one per lane, densely, from row 0 (banded_asm_kernel, top of the query loop).  Whatever gets
+// onto the list is scored exactly, so where the first pass stops is a pure performance choice.
 namespace {
 
-// Survivor-queue policy (measurement knobs; any value gives the same scores): a wave hands its survivors
-// to the queue when a test at or after row k + BGSA_BANDED_PUSH_ROW (default 40) finds at most
-// BGSA_BANDED_PUSH_MAX (default 4, 0 = never) lanes within the limit.
+// Regrouping policy (measurement knobs; any value gives the same scores): a wave puts its survivors on the
+// list when a test at or after row k + BGSA_BANDED_PUSH_ROW (default 56: random pairs are long dead by then)
+// finds at most BGSA_BANDED_PUSH_MAX (default 8, at most 32, 0 = never) lanes within the limit.
 int banded_push_max()
 {
     static const int v = [] {
         const char *e = getenv("BGSA_BANDED_PUSH_MAX");
-        const int x = e ? atoi(e) : 4;
-        return (x >= 0 && x <= 64) ? x : 4;
+        const int x = e ? atoi(e) : 8;
+        return (x >= 0 && x <= 32) ? x : 8;
     }();
     return v;
 }
@@ -350,8 +354,8 @@ int banded_push_row_offset()
 {
     static const int v = [] {
         const char *e = getenv("BGSA_BANDED_PUSH_ROW");
-        const int x = e ? atoi(e) : 40;
-        return x >= 0 ? x : 40;
+        const int x = e ? atoi(e) : 56;
+        return x >= 0 ? x : 56;
     }();
     return v;
 }
@@ -377,49 +381,25 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kBandedRefill, 40, stream, &fault)) return rc;
 
-    // Workspace: [streams: banded_stream_bound(len) * nq][queue counter: 256 B][queue: kBandedQueueBytes].
-    // A (wave, query) queues at most push_max pairs, so a slice of queries whose waves cannot overflow the
-    // queue is scored per pass: first pass, then the queued pairs, then the next slice.
-    unsigned char *ws = static_cast<unsigned char *>(d_workspace);
-    unsigned *queue_count = reinterpret_cast<unsigned *>(ws + banded_stream_bound(len) * static_cast<size_t>(nq));
-    uint2 *queue = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(queue_count) + 256);
-    int push_max = banded_push_max();
-    const int64_t capacity = static_cast<int64_t>(kBandedQueueBytes / sizeof(uint2));
-    int64_t slice = push_max > 0 ? capacity / (n_groups * push_max) : nq;
-    if (slice < q_tile) { push_max = 0; slice = nq; }   // a bucket too large for the queue: no compaction
-    slice = slice / q_tile * q_tile;
-    if (slice > nq) slice = nq;
-    const uint32_t push_row = static_cast<uint32_t>(k + banded_push_row_offset());
-    for (int q0 = 0; q0 < nq; q0 += static_cast<int>(slice)) {
-        const int nqs = static_cast<int>(q0 + slice <= nq ? slice : nq - q0);
-        dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
-                  static_cast<unsigned>((nqs + q_tile - 1) / q_tile));
-        if (grid.y > 65535u) {
-            set_error_text("banded: too many query tiles for one launch");
-            return BGSA_HIP_EUNSUPPORTED;
-        }
-        if (push_max > 0) BGSA_HIP_TRY(hipMemsetAsync(queue_count, 0, sizeof(unsigned), stream));
-        const unsigned char *streams = ws + static_cast<size_t>(q0) * stride;
-        int8_t *out = d_results + static_cast<size_t>(q0) * read_count;
-        if (k <= 15)
-            hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream, streams, d_peq, out,
-                               static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nqs, q_tile, k, stride,
-                               fault, q0, push_row, static_cast<uint32_t>(push_max), queue, queue_count);
-        else
-            hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream, streams, d_peq, out,
-                               static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nqs, q_tile, k, stride,
-                               fault, q0, push_row, static_cast<uint32_t>(push_max), queue, queue_count);
-        BGSA_HIP_TRY(hipGetLastError());
-        if (push_max > 0) {
-            if (k <= 15)
-                hipLaunchKernelGGL(banded_pairs_kernel<uint32_t>, dim3(kBandedPairGrid), dim3(256), 0, stream, d_content, d_peq,
-                                   d_results, len, static_cast<long long>(read_count), word_num, ref_start, k, queue, queue_count);
-            else
-                hipLaunchKernelGGL(banded_pairs_kernel<uint64_t>, dim3(kBandedPairGrid), dim3(256), 0, stream, d_content, d_peq,
-                                   d_results, len, static_cast<long long>(read_count), word_num, ref_start, k, queue, queue_count);
-            BGSA_HIP_TRY(hipGetLastError());
-        }
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("banded: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
     }
+    const uint32_t push_row = static_cast<uint32_t>(k + banded_push_row_offset());
+    const uint32_t push_max = static_cast<uint32_t>(banded_push_max());
+    if (k <= 15)
+        hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
+                           fault, d_content, ref_start, len, push_row, push_max);
+    else
+        hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
+                           fault, d_content, ref_start, len, push_row, push_max);
+    BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
 

@@ -113,10 +113,6 @@ constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill 
 // reference tests every 16 rows (banded/BGSA_CPU/config.h: batch_size); the errors never decrease, so
 // testing more often rejects exactly the same pairs, only sooner.
 constexpr int kBandedCheckRows = 8;
-// Survivor queue of the banded kernels (banded.hip): (query, subject) pairs a first-pass wave hands to the
-// dense second pass, 8 bytes each, behind the streams in the workspace; and the second pass's fixed grid.
-constexpr size_t kBandedQueueBytes = 64u << 20;
-constexpr int kBandedPairGrid = 2048;
 inline size_t banded_stream_bound(int len)
 {
     const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 + 4;

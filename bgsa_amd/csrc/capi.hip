@@ -213,8 +213,8 @@ static size_t plan_workspace_bytes(const Plan &plan, int ref_len, int read_len, 
         const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
         return blocked > in_memory ? blocked : in_memory;
     }
-    if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k: sized for the worst k; + the survivor queue
-        return banded_stream_bound(ref_len) * n_queries + 256 + kBandedQueueBytes;
+    if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k: sized for the worst k
+        return banded_stream_bound(ref_len) * n_queries;
     return stream_stride(ref_len) * static_cast<size_t>(n_queries);
 }
 
