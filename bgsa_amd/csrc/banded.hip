@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
 namespace {
 
 // Regrouping policy (measurement knobs; any value gives the same scores): a wave puts its survivors on the
-// list when a test at or after row k + BGSA_BANDED_PUSH_ROW (default 56: random pairs are long dead by then)
+// list when a test at or after row k + BGSA_BANDED_PUSH_ROW (default 48: random pairs are dead by then)
 // finds at most BGSA_BANDED_PUSH_MAX (default 8, at most 32, 0 = never) lanes within the limit.
 int banded_push_max()
 {
@@ -354,8 +354,8 @@ int banded_push_row_offset()
 {
     static const int v = [] {
         const char *e = getenv("BGSA_BANDED_PUSH_ROW");
-        const int x = e ? atoi(e) : 56;
-        return x >= 0 ? x : 56;
+        const int x = e ? atoi(e) : 48;
+        return x >= 0 ? x : 48;
     }();
     return v;
 }

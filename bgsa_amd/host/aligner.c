@@ -6,7 +6,7 @@
  *
  *   ./aligner -q <query file> -d <database file> -f <result file> [-N host threads]
  *             [-k threshold] [-a myers|banded|bitpal] [-n gpus] [-g first gpu | g0,g1,...]
- *             [-R ratio file] [-M match -I mismatch -G gap] [-s]
+ *             [-R ratio file] [-D] [-M match -I mismatch -G gap] [-s]
  *
  *   * input files: one sequence per line, all of one length (what `convert -f/-q` produces);
  *   * queries are mapped A,C,G,T,N -> 0..4 (file.c:117-140); the database is cut into read
@@ -28,7 +28,10 @@
  * backend's dispatch by ratio, BGSA_KNC/global.c:374-431, -R gives the ratios), each GPU scores
  * all queries against its slice, and a query block is written as device 0's [queries][reads]
  * tile, then device 1's, ... with the per-device counts recorded in `.info`
- * (BGSA_KNC/cal_mic.c:475-476,535-536).  One host thread drives all GPUs: launches and copies are
+ * (BGSA_KNC/cal_mic.c:475-476,535-536).  -D re-estimates the ratios after every bucket from the GPU time
+ * each device spent on its slice (HIP events around its kernels), with the reference's rule
+ * (adjust_device_ratio3, BGSA_KNC/global.c:120-168): device 0 is the unit, device i's ratio is scaled by
+ * t0/ti and averaged over the rounds so far with round r weighing r.  One host thread drives all GPUs: launches and copies are
  * asynchronous, and each GPU alternates between two streams so that the copy-out of block i
  * overlaps the kernel of block i+1.
  */
@@ -155,6 +158,7 @@ static void usage(void)
     printf("  -n <arg>\n\t Number of GPUs. Default 1. \n\n");
     printf("  -g <arg>\n\t First GPU index, or a comma separated list of GPU indices. Default 0. \n\n");
     printf("  -R <arg>\n\t File with one work ratio per GPU (one number per line). Default: equal. \n\n");
+    printf("  -D\n\t Dynamic ratios: re-balance the GPUs after every database bucket from their measured times. \n\n");
     exit(1);
 }
 
@@ -191,8 +195,40 @@ typedef struct {
     double ratio;
     void *d_rows, *d_peq, *d_q;
     void *stream[2], *d_out[2], *d_work[2];
-    int64_t first, count;      /* slice of the current bucket, in reads */
+    void *ev_start[2], *ev_stop[2]; /* around the scoring launches of the block in flight on stream[s] */
+    double gpu_ms;                  /* GPU time this device spent scoring the current bucket */
+    int delay;                      /* test knob BGSA_DEBUG_DEVICE_DELAY: every block is scored 1 + delay times */
+    int64_t first, count;           /* slice of the current bucket, in reads */
 } device_t;
+
+/* The reference's dynamic re-balancing (adjust_device_ratio3, BGSA_KNC/global.c:120-168): called after a
+ * bucket with the time every device needed for its slice.  Device 0 is the unit; device i's new ratio is
+ * its old one scaled by t0 / ti, then smoothed by a weighted mean over the rounds so far in which round r
+ * weighs r (the first round, measured with the initial guess, does not enter the mean, global.c:145). */
+#define MAX_ROUNDS 4096
+static double ratio_history[MAX_ROUNDS][MAX_DEV];
+static int ratio_rounds = 0;
+static void adjust_device_ratios(device_t *dev, int n, const double *times)
+{
+    double next[MAX_DEV];
+    next[0] = 1.0;
+    for (int i = 1; i < n; i++) next[i] = dev[i].ratio * times[0] / times[i];
+    const int rnd = ratio_rounds + 1; /* time_index of the reference */
+    if (rnd > 1) {
+        double total = (double)rnd, acc[MAX_DEV];
+        for (int i = 0; i < n; i++) acc[i] = next[i] * rnd;
+        for (int r = 1; r < rnd - 1; r++) {
+            for (int i = 1; i < n; i++) acc[i] += ratio_history[r][i] * (r + 1);
+            total += r + 1;
+        }
+        for (int i = 1; i < n; i++) next[i] = acc[i] / total;
+    }
+    if (ratio_rounds < MAX_ROUNDS) {
+        for (int i = 0; i < n; i++) ratio_history[ratio_rounds][i] = next[i];
+        ratio_rounds++;
+    }
+    for (int i = 0; i < n; i++) dev[i].ratio = next[i];
+}
 
 /* Cut `groups` subject groups into one contiguous run per device, proportional to the ratios.
  * The last device always gets a group: the padding reads at the end of a bucket are recorded in
@@ -233,6 +269,7 @@ int main(int argc, char **argv)
     int algo = BGSA_ALGO_MYERS, n_dev = 1, c;
     int sc_match = 2, sc_mismatch = -3, sc_gap = -5, sc_given = 0; /* the generator's -M -I -G (README.md:58-66) */
     int semi = 0;                                                   /* the generator's -s */
+    int dynamic = 0;                                                /* -D (BGSA_KNC/main.c:71-115) */
     threshold = HIP_BANDED_WORD_SIZE / 2 - 1; /* banded/BGSA_CPU/main.c:43 */
     while ((c = getopt(argc, argv, "t:q:d:f:n:N:M:I:G:k:a:g:R:Dsh")) != -1) {
         switch (c) {
@@ -254,7 +291,8 @@ int main(int argc, char **argv)
         case 'I': sc_mismatch = atoi(optarg); sc_given = 1; break;
         case 'G': sc_gap = atoi(optarg); sc_given = 1; break;
         case 's': semi = 1; break;
-        case 't': case 'D': break; /* KNC-only knobs: accepted, ignored */
+        case 'D': dynamic = 1; break;
+        case 't': break; /* KNC-only knob: accepted, ignored */
         default: usage();
         }
     }
@@ -291,6 +329,14 @@ int main(int argc, char **argv)
                     exit(1);
                 }
             fclose(fr);
+        }
+        if (getenv("BGSA_DEBUG_DEVICE_DELAY")) { /* tests of -D: "0,2,0" = device 1 scores every block three times */
+            const char *e = getenv("BGSA_DEBUG_DEVICE_DELAY");
+            for (int d = 0; d < n_dev && *e; d++) {
+                dev[d].delay = atoi(e);
+                while (*e && *e != ',') e++;
+                if (*e == ',') e++;
+            }
         }
     }
 
@@ -354,12 +400,17 @@ int main(int argc, char **argv)
         CK(bgsa_hip_malloc(&v->d_rows, (size_t)(cap * row)));
         CK(bgsa_hip_malloc(&v->d_peq, bgsa_hip_group_words(algo, word_num, threshold) * sizeof(hip_read_t) * (size_t)(cap / HIP_V_NUM)));
         CK(bgsa_hip_malloc(&v->d_q, (size_t)qsize + 8));
-        CK(bgsa_hip_memcpy_h2d(v->d_q, qbuf, (size_t)qsize, NULL));
         for (int s = 0; s < 2; s++) {
             CK(bgsa_hip_stream_create(&v->stream[s]));
             CK(bgsa_hip_malloc(&v->d_out[s], (size_t)REF_BUCKET_COUNT * (size_t)cap * esz));
             CK(bgsa_hip_malloc(&v->d_work[s], work_bytes ? work_bytes : 8));
+            CK(bgsa_hip_event_create(&v->ev_start[s]));
+            CK(bgsa_hip_event_create(&v->ev_stop[s]));
         }
+        /* on the device's own stream, and complete before anything is launched (the streams do not
+         * synchronise with the NULL stream) */
+        CK(bgsa_hip_memcpy_h2d(v->d_q, qbuf, (size_t)qsize, v->stream[0]));
+        CK(bgsa_hip_stream_synchronize(v->stream[0]));
     }
 
     ring_t ring;
@@ -433,6 +484,11 @@ int main(int argc, char **argv)
                 for (int d = 0; d < n_dev; d++) {
                     CK(bgsa_hip_set_device(dev[d].gpu));
                     CK(bgsa_hip_stream_synchronize(dev[d].stream[s]));
+                    if (dev[d].count) {
+                        float ms = 0;
+                        CK(bgsa_hip_event_elapsed_ms(dev[d].ev_start[s], dev[d].ev_stop[s], &ms));
+                        dev[d].gpu_ms += ms;
+                    }
                 }
                 ring_publish(&ring, slot_of[s], bytes_of[s]);
                 slot_of[s] = -1;
@@ -452,9 +508,12 @@ int main(int argc, char **argv)
                 device_t *v = &dev[d];
                 if (!v->count) continue;
                 CK(bgsa_hip_set_device(v->gpu));
-                CK(bgsa_hip_cal_align_score_dev(algo, (const char *)v->d_q, (const hip_read_t *)v->d_peq, v->d_out[s],
-                                                ref_len, read_len, v->count, (int)ref_start, (int)ref_end, word_num,
-                                                threshold, v->d_work[s], work_bytes, v->stream[s]));
+                CK(bgsa_hip_event_record(v->ev_start[s], v->stream[s]));
+                for (int rep = 0; rep <= v->delay; rep++)
+                    CK(bgsa_hip_cal_align_score_dev(algo, (const char *)v->d_q, (const hip_read_t *)v->d_peq, v->d_out[s],
+                                                    ref_len, read_len, v->count, (int)ref_start, (int)ref_end, word_num,
+                                                    threshold, v->d_work[s], work_bytes, v->stream[s]));
+                CK(bgsa_hip_event_record(v->ev_stop[s], v->stream[s]));
                 /* device tiles one after another inside the block (cal_mic.c:535-536) */
                 CK(bgsa_hip_memcpy_d2h(dst + (size_t)nq * (size_t)v->first * esz, v->d_out[s],
                                        (size_t)nq * (size_t)v->count * esz, v->stream[s]));
@@ -464,6 +523,29 @@ int main(int argc, char **argv)
         }
         cal_time += now() - t0 - stalled; /* time with scoring work in flight on the GPUs */
         subjects_done += count;
+        for (int d = 0; d < n_dev; d++) { /* a damaged query stream is an error, not a wrong score (bgsa_hip.h) */
+            CK(bgsa_hip_set_device(dev[d].gpu));
+            if (bgsa_hip_stream_faults(1) != 0) die("stream fault");
+        }
+        if (dynamic && n_dev > 1) {
+            double times[MAX_DEV];
+            int usable = 1;
+            for (int d = 0; d < n_dev; d++) {
+                /* what the reference measures is the time of device i for a share proportional to its ratio;
+                 * slices are whole groups, so take the time per read times the ratio instead of the raw time */
+                times[d] = dev[d].count ? dev[d].gpu_ms / (double)dev[d].count * dev[d].ratio : 0;
+                if (times[d] <= 0) usable = 0;
+            }
+            if (usable) {
+                adjust_device_ratios(dev, n_dev, times);
+                printf("bucket %d: device times per read", b);
+                for (int d = 0; d < n_dev; d++) printf(" %.3fus", 1e3 * dev[d].gpu_ms / (double)dev[d].count);
+                printf(" -> ratios");
+                for (int d = 0; d < n_dev; d++) printf(" %.3f", dev[d].ratio);
+                printf("\n");
+            }
+        }
+        for (int d = 0; d < n_dev; d++) dev[d].gpu_ms = 0;
     }
     pthread_mutex_lock(&ring.lock);
     ring.done = 1;
@@ -499,6 +581,7 @@ int main(int argc, char **argv)
         bgsa_hip_free(v->d_rows); bgsa_hip_free(v->d_peq); bgsa_hip_free(v->d_q);
         for (int s = 0; s < 2; s++) {
             bgsa_hip_stream_destroy(v->stream[s]);
+            bgsa_hip_event_destroy(v->ev_start[s]); bgsa_hip_event_destroy(v->ev_stop[s]);
             bgsa_hip_free(v->d_out[s]); bgsa_hip_free(v->d_work[s]);
         }
     }

@@ -17,7 +17,7 @@ ROOT = HOST.parent.parent
 ALGO_FLAG = {"original_cpu": "myers", "original_avx2": "bitpal", "banded_cpu": "banded"}
 
 
-def _run_cli(tmp_path, g, bucket_bytes=None, converter=None, extra_args=()):
+def _run_cli(tmp_path, g, bucket_bytes=None, converter=None, extra_args=(), env_extra=None):
     (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
     (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
     cmd = [str(HOST / "aligner"), "-q", "query.txt", "-d", "subject.txt", "-f", "result.txt",
@@ -25,7 +25,7 @@ def _run_cli(tmp_path, g, bucket_bytes=None, converter=None, extra_args=()):
     if g["k"] >= 0:
         cmd += ["-k", str(g["k"])]
     cmd += list(extra_args)
-    env = dict(os.environ)
+    env = dict(os.environ, **(env_extra or {}))
     if bucket_bytes:
         env["BGSA_READ_BUCKET_SIZE"] = str(bucket_bytes)
     p = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True)
@@ -97,6 +97,32 @@ def test_cli_three_devices_ratios_buckets_and_blocks(tmp_path, oracle):
     assert all(int(x) % 64 == 0 for c in counts for x in c)
     assert counts[0][1] > counts[0][0] > counts[0][2]                    # follows the ratios
     assert np.frombuffer(info[16 + 2 * rec + 24: 16 + 3 * rec], dtype=np.int32)[0] == 24
+
+
+def test_cli_dynamic_ratios_follow_device_times(tmp_path, oracle):
+    """-D (the KNC backend's dynamic mode, adjust_device_ratio3, BGSA_KNC/global.c:120-168): three device
+    entries, the middle one made four times slower (it scores every block four times), six read buckets:
+    after the first bucket its slice shrinks to about a quarter, the scores do not change."""
+    q = oracle.gen_reads(193, 150, 150)
+    s = oracle.gen_reads(194, 6 * 3840, 150)
+    g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
+    got, report = _run_cli(tmp_path, g, bucket_bytes=3840 * 151 + 10, extra_args=["-g", "0,0,0", "-D"],
+                           env_extra={"BGSA_DEBUG_DEVICE_DELAY": "0,3,0"})
+    assert np.array_equal(got, oracle.myers64(q, s))
+    assert "-> ratios" in report
+    info = (tmp_path / "result.txt.info").read_bytes()
+    n_buckets, n_dev = np.frombuffer(info[:8], dtype=np.int32)
+    assert (n_buckets, n_dev) == (6, 3)
+    rec = 8 * 3 + 4
+    counts = np.array([np.frombuffer(info[16 + b * rec: 16 + b * rec + 24], dtype=np.int64) for b in range(6)])
+    assert (counts.sum(axis=1) == 3840).all() and (counts % 64 == 0).all()
+    assert counts[0][0] == counts[0][1] == counts[0][2]                   # bucket 0: the initial equal split
+    for b in range(2, 6):                                                  # from then on the slow device gets far less
+        assert counts[b][1] < 0.6 * counts[b][0] and counts[b][1] < 0.6 * counts[b][2], counts
+    # without -D nothing moves
+    got2, report2 = _run_cli(tmp_path, g, bucket_bytes=3840 * 151 + 10, extra_args=["-g", "0,0,0"],
+                             env_extra={"BGSA_DEBUG_DEVICE_DELAY": "0,3,0"})
+    assert np.array_equal(got2, got) and "-> ratios" not in report2
 
 
 def test_cli_more_devices_than_groups(tmp_path, oracle):
