@@ -78,7 +78,16 @@ __global__ __launch_bounds__(256) void preprocess_global_lds_kernel(const char *
         const int n16 = (skew + group_bytes + 15) / 16;
         for (int i = lane; i < n16; i += 64) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (aligned + 16LL * i + 16 <= ((total_bytes + 15) & ~15LL)) v = src[i];  // stays inside the allocation's last line
+            const long long at = aligned + 16LL * i;
+            if (at + 16 <= total_bytes) {
+                v = src[i];
+            } else if (at < total_bytes) {   // the input's last, partial 16-byte line: not one byte past avail_bytes
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int b = 0; b < 16; b++)
+                    if (at + b < total_bytes) w[b >> 2] |= static_cast<uint32_t>(static_cast<unsigned char>(rows[at + b])) << (8 * (b & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
             reinterpret_cast<uint4 *>(mine)[i] = v;
         }
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,23 @@
+#!/bin/bash
+# What a BGSA maintainer sees after dropping the library in (GPU box): the reference's OWN host pipeline
+# (main.c / file.c / thread.c / cal_cpu.c, unmodified, oracle/_ref/original_hip/aligner) and this repo's
+# command line, on the same synthetic files, each printing the reference-style report (cal / Total GCUPS).
+#   bash scripts/drop_in_throughput.sh [queries] [subjects] [length] [host threads]
+NQ=${1:-1000}; NS=${2:-1000000}; LEN=${3:-150}; THREADS=${4:-16}
+D=/dev/shm/bgsa_dropin_$$; mkdir -p $D
+python3 - <<PY
+import numpy as np
+rng = np.random.default_rng(1)
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+for name, n in (("query", $NQ), ("subject", $NS)):
+    rows = np.full((n, $LEN + 1), 10, dtype=np.uint8)
+    rows[:, :$LEN] = acgt[rng.integers(0, 4, (n, $LEN))]
+    rows.tofile("$D/" + name + ".txt")
+PY
+here=$(pwd)
+echo "== reference host files on libbgsa_hip.so (align_hip seam from its OpenMP loop), -N $THREADS =="
+( cd $D && /usr/bin/time -f "wall %es" timeout -k 10 600 $here/oracle/_ref/original_hip/aligner -q query.txt -d subject.txt -f result_ref.txt -N $THREADS 2>&1 | grep -E "GCUPS|total time|cal_total|wall|Error" )
+echo "== bgsa_amd/host/aligner (device-resident pipeline on the same C ABI) =="
+( cd $D && /usr/bin/time -f "wall %es" timeout -k 10 600 $here/bgsa_amd/host/aligner -q query.txt -d subject.txt -f result_hip.txt 2>&1 | grep -E "GCUPS|total time|cal_total|wall|Error" )
+cmp $D/result_ref.txt $D/result_hip.txt && echo "result files identical"
+rm -rf $D

@@ -778,3 +778,44 @@ def test_measurement_knobs_do_not_change_results(env):
     p = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, str(root)], env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "knobs ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+# ---- the streamed gather on one GPU: the side stream moves block i while the compute stream scores block i+1 ----
+def test_gather_stream_overlaps_the_next_block(oracle):
+    import time
+    import torch
+    from bgsa_amd.multi_gpu import ScoreGatherStream
+    nq, ns, rows = 1200, 64 * 4096, 100
+    q = oracle.gen_reads(301, nq, 150)
+    s = oracle.gen_reads(302, ns, 150)
+    a = B.DeviceAligner(B.ALGO_MYERS)
+    a.set_queries(q)
+    a.set_subjects(s)
+    out = torch.empty((nq, ns), dtype=torch.int16, device="cuda:0")
+    got = []
+    gs = ScoreGatherStream(None, "cuda:0", [ns], torch.int16, block_rows=rows,
+                           on_block=lambda i, t: got.append((i, t[: 64 * rows].cpu().numpy().copy())))
+    a.score(0, rows, out=out[:rows])                      # warm-up (workspace allocation)
+    torch.cuda.synchronize()
+    k_done = [torch.cuda.Event(enable_timing=True) for _ in range(nq // rows)]
+    start = torch.cuda.Event(enable_timing=True)
+    start.record()
+    t0 = time.perf_counter()
+    for b in range(nq // rows):
+        a.score(b * rows, (b + 1) * rows, out=out[b * rows:(b + 1) * rows])
+        k_done[b].record()
+        gs.submit(out[b * rows:(b + 1) * rows])
+    issue_s = time.perf_counter() - t0
+    gs.drain()
+    torch.cuda.synchronize()
+    gpu_s = start.elapsed_time(k_done[-1]) / 1e3
+    # the blocks arrive complete, in order, in the reference's block layout (one device: [rows][ns] flat)
+    want = oracle.myers64(q[:rows], s[:64])
+    assert [i for i, _ in got] == list(range(nq // rows))
+    assert np.array_equal(got[0][1].reshape(-1)[: 64], out[0, :64].cpu().numpy())
+    assert np.array_equal(out[:rows, :64].cpu().numpy(), want)
+    # the compute stream never waited for a transfer: back-to-back kernels, issued ahead of the GPU except where
+    # the consumer callback (a device-to-host copy here, as a writer thread would do) holds the host
+    per_kernel = start.elapsed_time(k_done[0]) / 1e3
+    assert gpu_s < 1.5 * per_kernel * (nq // rows) + 0.05
+    assert issue_s < gpu_s * 3 + 0.5
