@@ -197,6 +197,7 @@ static int make_plan(const bgsa_hip_params_t &p, Plan *plan)
 static bool plan_beyond_registers(const Plan &plan, int word_num)
 {
     if (plan.kernel == BGSA_ALGO_BITPAL) return word_num > plan.set->max_plain;
+    if (plan.kernel == BGSA_ALGO_MYERS && plan.semi) return word_num > myers_semi_max_plain_words();
     return plan.kernel == BGSA_ALGO_MYERS && word_num > myers_max_plain_words();
 }
 

@@ -656,6 +656,14 @@ def main() -> int:
                  "                                                    const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PAIR_NW:
         parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}", R.myers_body(nw, 1), 2 * nw, nw))
+    parts.append("\n// Semi-global (generator -m 0 -s): rows_ir.py: myers_semi_body — the subject right-aligned in its NW words,\n"
+                 "// state = {VP, VN} x NW, then D[i][n] (running) and its minimum; 10 VALU per word + 3 per row.\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ int myers_semi_rows_asm(uint32_t (&state)[2 * NW + 2],\n"
+                 "                                                   const uint32_t (&P)[5][NW],\n"
+                 "                                                   const unsigned long long stream, const int n_windows);\n")
+    for nw in MYERS_NW:
+        parts.append(gen_function("myers_semi_rows_asm", f"{nw}", R.myers_semi_body(nw), 2 * nw + 2, nw))
     parts.append("\n// Long subjects (NW 26..32; the widths below 26 serve the column-block kernel and A/B runs): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ int myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"

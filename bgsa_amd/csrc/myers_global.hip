@@ -224,6 +224,69 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     }
 }
 
+// ---- semi-global (the generator's -m 0 -s, MyersGenerator.java:56-223) -------------------------------------
+// The subject end to end inside the query: D[i][0] = 0 for every query row, result = -min over rows of D[i][n].
+// What the semi-global kernels do to a subject once per task (rows_ir.py: semi_align): its n columns are moved
+// to the top of the `total_words` words they occupy, so that column n is bit 31 of the last word and the
+// HP / HN shift chains drop D[i][n] - D[i-1][n] out as their final carries; the s = 32 * total_words - n unused
+// low columns match every character and start at VP = 0, which keeps them at D = 0 — the row edge of the mode,
+// delivered to the first real column.
+// Aligned word `aw` of class plane `row` (source words row[0 .. word_num), stride kLanes), s = 32 q + r:
+__device__ __forceinline__ uint32_t semi_aligned_word(const uint32_t *row, int word_num, int aw, int q, int r)
+{
+    const int hi = aw - q, lo = aw - q - 1;
+    const uint32_t a = (hi >= 0 && hi < word_num) ? row[hi * kLanes] : 0u;
+    const uint32_t b = (r != 0 && lo >= 0 && lo < word_num) ? row[lo * kLanes] : 0u;
+    return r ? ((a << r) | (b >> (32 - r))) : a;
+}
+// the unused low columns of aligned word aw (wave-uniform)
+__device__ __forceinline__ uint32_t semi_dummy_mask(int aw, int s)
+{
+    const int d = s - 32 * aw;
+    return d >= 32 ? ~0u : (d <= 0 ? 0u : ((1u << d) - 1u));
+}
+
+// Subjects up to 768 bp (the widths with resident Peq planes): generated asm row loop of myers_semi_body,
+// 10 VALU per word + 3 per row.
+template <int NW>
+__global__ __launch_bounds__(256) void myers_semi_asm_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
+    int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (group >= n_groups) return;
+    const int s_cols = 32 * NW - read_len, sq = s_cols >> 5, sr = s_cols & 31;
+
+    uint32_t P[kChars][NW];
+    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+#pragma unroll
+    for (int c = 0; c < kChars; c++)
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            P[c][w] = semi_aligned_word(g + static_cast<size_t>(c) * word_num * kLanes, word_num, w, sq, sr) | semi_dummy_mask(w, s_cols);
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        uint32_t st[2 * NW + 2];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            st[2 * w] = ~semi_dummy_mask(w, s_cols);
+            st[2 * w + 1] = 0u;
+        }
+        st[2 * NW] = st[2 * NW + 1] = static_cast<uint32_t>(read_len);   // D[0][n] = n (genSemiGlobal: min_score = score = read_len)
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        note_stream_fault(fault_word, myers_semi_rows_asm<NW>(st, P, uniform_u64(s),
+                                                              __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
+        dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(-static_cast<int>(st[2 * NW + 1]));
+    }
+}
+
 // Long subjects (769..1024 bp; 257..1024 before the Peq-resident kernels were widened): the wave turns its five Peq planes into the subject's 3-bit
 // character-code planes once per task (B0 = C|T, B1 = G|T, B2 = N) and the row body rebuilds the
 // match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 11 VALU per
@@ -281,7 +344,9 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
 // through its carry buffer ([32-row chunk][add, HP, HN][lane] words in the workspace, first row in
 // bit 31 — rows_ir.py: myers_block_body).  A fixed number of workgroups loops over the tasks so
 // that the buffer count does not grow with the problem.
-template <int NW, bool PEQ = false>
+// SEMI (PEQ blocks only): the subject right-aligned over the n_blocks x NW words (semi_aligned_word above),
+// HP carry-in 0, and D[i][n] followed through the last block's HP / HN carry-out words after the row loop.
+template <int NW, bool PEQ = false, bool SEMI = false>
 __global__ __launch_bounds__(256) void myers_blocked_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
     uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
@@ -296,6 +361,8 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
     const int q_tiles = (n_queries + q_tile - 1) / q_tile;
     const long long n_tasks = static_cast<long long>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock) * q_tiles;
     const int tail_rows = ref_len & 31;
+    static_assert(!SEMI || PEQ, "semi-global column blocks use the Peq-resident body");
+    const int s_cols = 32 * NW * n_blocks - read_len, sq = s_cols >> 5, sr = s_cols & 31;   // SEMI: unused low columns
     dephase_persistent_workgroup();
 
     for (long long task = next_blocked_task(task_counter); task < n_tasks; task = next_blocked_task(task_counter)) {
@@ -306,10 +373,10 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
         const int q0 = tile * q_tile;
         const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
         for (int q = q0; q < q1; q++) {
-            // carry-in of block 0: addition 0, HP 1 (the row edge D[i][0] - D[i-1][0] = +1), HN 0
+            // carry-in of block 0: addition 0, HP 1 (the row edge D[i][0] - D[i-1][0] = +1; semi-global: 0), HN 0
             for (int c = 0; c < n_chunks; c++) {
                 carry[(c * 3 + 0) * kLanes + lane] = 0u;
-                carry[(c * 3 + 1) * kLanes + lane] = ~0u;
+                carry[(c * 3 + 1) * kLanes + lane] = SEMI ? 0u : ~0u;
                 carry[(c * 3 + 2) * kLanes + lane] = 0u;
             }
             const unsigned long long s =
@@ -327,7 +394,13 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                     const int gwc = gw < word_num ? gw : word_num - 1;
                     const uint32_t keep = gw < word_num ? ~0u : 0u;
 #pragma unroll
-                    for (int c = 0; c < kChars; c++) p[c] = g[(c * word_num + gwc) * kLanes] & keep;
+                    for (int c = 0; c < kChars; c++) {
+                        if constexpr (SEMI)
+                            p[c] = semi_aligned_word(g + static_cast<size_t>(c) * word_num * kLanes, word_num, gw, sq, sr) |
+                                   semi_dummy_mask(gw, s_cols);
+                        else
+                            p[c] = g[(c * word_num + gwc) * kLanes] & keep;
+                    }
                     if constexpr (PEQ) {
 #pragma unroll
                         for (int c = 0; c < kChars; c++) Pq[c][w] = p[c];
@@ -340,7 +413,7 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                 uint32_t st[2 * NW + 6];
 #pragma unroll
                 for (int w = 0; w < NW; w++) {
-                    st[2 * w] = ~0u;
+                    st[2 * w] = SEMI ? ~semi_dummy_mask(blk * NW + w, s_cols) : ~0u;
                     st[2 * w + 1] = 0u;
                 }
 #pragma unroll
@@ -369,6 +442,20 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                     const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
                     score += __popc(st[2 * w] & m) - __popc(st[2 * w + 1] & m);
                 }
+            }
+            if constexpr (SEMI) {
+                // The carry buffer now holds what left the LAST block: per 32-row chunk the HP and HN bits of
+                // column n, first row in bit 31 — D[i][n] - D[i-1][n] row by row.  D[0][n] = n.
+                int run = read_len, best = read_len;
+                for (int c = 0; c < n_chunks; c++) {
+                    const uint32_t hpw = carry[(c * 3 + 1) * kLanes + lane], hnw = carry[(c * 3 + 2) * kLanes + lane];
+                    const int rows = ref_len - 32 * c < 32 ? ref_len - 32 * c : 32;
+                    for (int b2 = 0; b2 < rows; b2++) {
+                        run += static_cast<int>((hpw >> (31 - b2)) & 1u) - static_cast<int>((hnw >> (31 - b2)) & 1u);
+                        best = run < best ? run : best;
+                    }
+                }
+                score = best;
             }
             out[static_cast<size_t>(q) * ld + static_cast<size_t>(group) * kLanes + lane] = static_cast<int16_t>(-score);
         }
@@ -438,6 +525,31 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
 }
 
 template <int NW>
+int launch_semi_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
+                    int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
+                    void *d_workspace, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    const int q_tile = pick_q_tile(nq, n_groups);
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("myers: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
+    hipLaunchKernelGGL((myers_semi_asm_kernel<NW>), grid, dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                       read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+template <int NW>
 int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                   void *d_workspace, hipStream_t stream)
@@ -463,7 +575,7 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
     return BGSA_HIP_OK;
 }
 
-template <int NW, bool PEQ = false>
+template <int NW, bool PEQ = false, bool SEMI = false>
 int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
                    int64_t read_count, int ref_start, int ref_end, int word_num, int n_blocks, void *d_workspace,
                    hipStream_t stream)
@@ -478,7 +590,7 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     BGSA_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kCodeRefill, -1, stream, &fault)) return rc;
-    hipLaunchKernelGGL((myers_blocked_kernel<NW, PEQ>), dim3(blocked_workgroups()), dim3(256), 0, stream,
+    hipLaunchKernelGGL((myers_blocked_kernel<NW, PEQ, SEMI>), dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
                        blocked_q_tile(nq, read_count / kLanes),
@@ -580,6 +692,9 @@ int myers_peq_max_words()
     return limit;
 }
 
+// Semi-global: widest subject (words) scored by myers_semi_asm_kernel; wider ones run as column blocks.
+int myers_semi_max_plain_words() { return myers_peq_max_words(); }
+
 int pick_peq_nw(int word_num)
 {
     if (word_num > myers_peq_max_words()) return -1;
@@ -593,7 +708,13 @@ const char *myers_kernel_name(int word_num, int semi_global)
     static thread_local char name[64];
     const int nw = pick_nw(word_num);
     if (semi_global) {
-        snprintf(name, sizeof name, "myers_global_kernel<%d, 1, true>", nw);
+        int n_blocks = 0;
+        if (myers_impl() != 0)
+            snprintf(name, sizeof name, "myers_global_kernel<%d, 1, true>", nw);
+        else if (word_num <= myers_semi_max_plain_words())
+            snprintf(name, sizeof name, "myers_semi_asm_kernel<%d>", pick_peq_nw(word_num));
+        else
+            snprintf(name, sizeof name, "myers_blocked_kernel<%d, true, true>", pick_peq_block_nw(word_num, &n_blocks));
         return name;
     }
     if (word_num > myers_max_plain_words()) {
@@ -618,7 +739,34 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
                  void *d_workspace, hipStream_t stream, int semi_global)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
-    if (semi_global) {  // compiler-scheduled kernel only: subjects up to 1024 bp
+    if (semi_global && myers_impl() == 0) {
+        // generated-asm kernels: resident Peq planes up to 24 words, column blocks (any length) beyond
+        if (word_num <= myers_semi_max_plain_words()) {
+            switch (pick_peq_nw(word_num)) {
+#define BGSA_SEMI_CASE(N)                                                                       \
+    case N:                                                                                     \
+        return launch_semi_asm<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,   \
+                                  ref_start, ref_end, word_num, d_workspace, stream);
+                BGSA_SEMI_CASE(1) BGSA_SEMI_CASE(2) BGSA_SEMI_CASE(3) BGSA_SEMI_CASE(4) BGSA_SEMI_CASE(5)
+                BGSA_SEMI_CASE(6) BGSA_SEMI_CASE(7) BGSA_SEMI_CASE(8) BGSA_SEMI_CASE(10) BGSA_SEMI_CASE(12)
+                BGSA_SEMI_CASE(14) BGSA_SEMI_CASE(16) BGSA_SEMI_CASE(18) BGSA_SEMI_CASE(20) BGSA_SEMI_CASE(22)
+                BGSA_SEMI_CASE(24)
+#undef BGSA_SEMI_CASE
+            default: break;
+            }
+        }
+        int n_blocks = 0;
+        switch (pick_peq_block_nw(word_num, &n_blocks)) {
+#define BGSA_BLOCK_CASE(N)                                                                       \
+    case N:                                                                                      \
+        return launch_blocked<N, true, true>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
+                                             ref_end, word_num, n_blocks, d_workspace, stream);
+            BGSA_BLOCK_CASE(12) BGSA_BLOCK_CASE(14) BGSA_BLOCK_CASE(16) BGSA_BLOCK_CASE(18) BGSA_BLOCK_CASE(20)
+#undef BGSA_BLOCK_CASE
+        default: break;
+        }
+    }
+    if (semi_global) {  // BGSA_MYERS_IMPL=c: the compiler-scheduled kernel, subjects up to 1024 bp (A/B reference)
         switch (pick_nw(word_num)) {
 #define BGSA_CASE(N)                                                                            \
     case N:                                                                                     \
@@ -629,7 +777,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             BGSA_CASE(20) BGSA_CASE(24) BGSA_CASE(28) BGSA_CASE(32)
 #undef BGSA_CASE
         default:
-            set_error_text("myers: semi-global scoring is implemented for subjects up to 1024 bp");
+            set_error_text("myers: the compiler-scheduled semi-global kernel (BGSA_MYERS_IMPL=c) covers subjects up to 1024 bp");
             return BGSA_HIP_EUNSUPPORTED;
         }
     }

@@ -75,6 +75,10 @@ class Body:
     def ADDC(self, d, a, b): return self._emit("addc", d, a, b)       # d = a + b + VCC, VCC = carry out
     def SETC1(self): return self._emit("setc1", "")                    # VCC = all ones (carry-in 1)
 
+    def ADDCZ(self, d): return self._emit("addcz", d, d)              # d = d + VCC  (v_addc_co_u32 d, vcc, 0, d, vcc)
+    def SUBBZ(self, d): return self._emit("subbz", d, d)              # d = d - VCC  (v_subbrev_co_u32 d, vcc, 0, d, vcc)
+    def MINU(self, d, a, b): return self._emit("minu", d, a, b)       # d = min(a, b), unsigned
+
     def ADD(self, d, a, b): return self._emit("add", d, a, b)          # d = a + b, no carry
     def LSHR1(self, d, a): return self._emit("lshr1", d, a)            # d = a >> 1 (slow class)
     def ALIGNBIT(self, d, hi, lo, sh): return self._emit("alignbit", d, hi, lo, sh)  # ({hi,lo} >> sh)[31:0], sh scalar
@@ -183,6 +187,15 @@ class Body:
                     wide = wide + vcc.astype(np.uint64)
                 vcc = (wide >> np.uint64(32)) != 0
                 wr(op.dst, wide & np.uint64(0xFFFFFFFF))
+            elif k == "addcz":
+                wide = s[0].astype(np.uint64) + vcc.astype(np.uint64)
+                vcc = (wide >> np.uint64(32)) != 0
+                wr(op.dst, wide & np.uint64(0xFFFFFFFF))
+            elif k == "subbz":
+                borrow = vcc & (s[0] == 0)
+                wr(op.dst, (s[0].astype(np.int64) - vcc.astype(np.int64)) & np.int64(0xFFFFFFFF))
+                vcc = borrow
+            elif k == "minu": wr(op.dst, np.minimum(s[0], s[1]))
             else:
                 raise ValueError(k)
 
@@ -200,7 +213,7 @@ class Body:
                 continue
             r = [reg_name(x) for x in op.srcs]
             d = reg_name(op.dst)
-            if k == "addc" and since_vcc_write < 2:
+            if k in ("addc", "addcz", "subbz") and since_vcc_write < 2:
                 lines.append(f"s_nop {1 - since_vcc_write}")
                 since_vcc_write = 2
             if k == "and": lines.append(f"v_and_b32 {d}, {r[0]}, {r[1]}")
@@ -215,9 +228,12 @@ class Body:
             elif k == "match3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm[cls]:02x}")
             elif k == "add_co": lines.append(f"v_add_co_u32 {d}, vcc, {r[0]}, {r[1]}")
             elif k == "addc": lines.append(f"v_addc_co_u32 {d}, vcc, {r[0]}, {r[1]}, vcc")
+            elif k == "addcz": lines.append(f"v_addc_co_u32 {d}, vcc, 0, {r[0]}, vcc")
+            elif k == "subbz": lines.append(f"v_subbrev_co_u32 {d}, vcc, 0, {r[0]}, vcc")
+            elif k == "minu": lines.append(f"v_min_u32 {d}, {r[0]}, {r[1]}")
             else:
                 raise ValueError(k)
-            since_vcc_write = 0 if k in ("add_co", "addc") else since_vcc_write + 1
+            since_vcc_write = 0 if k in ("add_co", "addc", "addcz", "subbz") else since_vcc_write + 1
         return lines
 
 
@@ -228,10 +244,10 @@ def count_hazard_nops(body: "Body") -> int:
         if op.kind == "setc1":
             since = 0
             continue
-        if op.kind == "addc" and since < 2:
+        if op.kind in ("addc", "addcz", "subbz") and since < 2:
             nops += 1
             since = 2
-        since = 0 if op.kind in ("add_co", "addc") else since + 1
+        since = 0 if op.kind in ("add_co", "addc", "addcz", "subbz") else since + 1
     return nops
 
 
@@ -252,9 +268,9 @@ def schedule(body: "Body", window: int = 48) -> "Body":
     for i, op in enumerate(ops):
         reads = [r for r in op.srcs if r]
         writes = [op.dst] if op.dst else []
-        if op.kind == "addc":
+        if op.kind in ("addc", "addcz", "subbz"):
             reads.append("VCC")
-        if op.kind in ("add_co", "addc", "setc1"):
+        if op.kind in ("add_co", "addc", "setc1", "addcz", "subbz"):
             writes.append("VCC")
         for r in reads:
             if r in last_write:
@@ -283,8 +299,8 @@ def schedule(body: "Body", window: int = 48) -> "Body":
         while oldest < n and done[oldest]:
             oldest += 1
         cands = [i for i in ready if i < oldest + window] or ready[:1]
-        chain = [i for i in cands if ops[i].kind in ("addc", "add_co", "setc1")]
-        plain = [i for i in cands if ops[i].kind != "addc"]
+        chain = [i for i in cands if ops[i].kind in ("addc", "add_co", "setc1", "addcz", "subbz")]
+        plain = [i for i in cands if ops[i].kind not in ("addc", "addcz", "subbz")]
         if since >= 2 and chain:
             pick = chain[0]                      # the chain is the critical path: keep it moving
         elif since < 2 and plain:
@@ -295,7 +311,7 @@ def schedule(body: "Body", window: int = 48) -> "Body":
         ready.remove(pick)
         done[pick] = True
         order.append(pick)
-        since = 0 if ops[pick].kind in ("add_co", "addc", "setc1") else since + 1
+        since = 0 if ops[pick].kind in ("add_co", "addc", "setc1", "addcz", "subbz") else since + 1
         for s in succs[pick]:
             remaining[s] -= 1
             if remaining[s] == 0:
@@ -341,6 +357,87 @@ def myers_body(nw: int, groups: int = 1) -> Body:
             b.AND(M(w), D(w), HP(w))
             b.BITOP3(P(w), D(w), HP(w), HN(w), lambda d, hp, hn: ~(d | hp) | hn)
     return b
+
+
+def myers_semi_body(nw: int) -> Body:
+    """Semi-global Myers (generator -m 0 -s, MyersGenerator.java:56-223): the subject end to end inside the
+    query — D[i][0] = 0 for every query row i, result = min over i of D[i][n].  The body is myers_body with
+      * carry-in 0 instead of 1 for the HP shift (the row edge D[i][0] - D[i-1][0] = 0), and
+      * the subject RIGHT-ALIGNED in its words (the kernel shifts the masks once per task; the unused low
+        columns match every character and start at VP = 0, so they stay at D = 0 and hand the row edge to
+        the first real column), which puts the last subject column at bit 31 of the last word: the carries
+        that leave the HP and HN shift chains ARE D[i][n] - D[i-1][n], added to / subtracted from the running
+        score with one add-with-carry each, plus one v_min for the best score — 3 instructions per row on top of
+        the 10 per word, nothing extracted bit by bit.
+    State: myers_body's, then S[2nw] = D[i][n] (running), S[2nw+1] = its minimum so far."""
+    b = Body()
+    P = lambda w: f"S{w * 2}"
+    M = lambda w: f"S{w * 2 + 1}"
+    E = lambda w: f"E{w}"
+    D = lambda w: f"d{w}"
+    HP = lambda w: f"hp{w}"
+    HN = lambda w: f"hn{w}"
+    RUN, BEST = f"S{2 * nw}", f"S{2 * nw + 1}"
+    for w in range(nw):
+        b.AND(D(w), P(w), E(w))
+        (b.ADD_CO if w == 0 else b.ADDC)(D(w), D(w), P(w))
+        b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
+        b.OR(D(w), D(w), E(w))
+    for w in range(nw):  # HP << 1 across words, carry-in 0
+        b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
+        b.AND(HN(w), D(w), P(w))
+        (b.ADD_CO if w == 0 else b.ADDC)(HP(w), HP(w), HP(w))
+    b.AND(M(0), D(0), HP(0))            # two instructions behind the chain's last link
+    if nw > 1:
+        b.AND(M(1), D(1), HP(1))
+    b.ADDCZ(RUN)                        # + the HP bit that left the last column
+    for w in range(nw):  # HN << 1 across words, then the new vertical deltas
+        (b.ADD_CO if w == 0 else b.ADDC)(HN(w), HN(w), HN(w))
+        if w >= 2:
+            b.AND(M(w), D(w), HP(w))
+        b.BITOP3(P(w), D(w), HP(w), HN(w), lambda d, hp, hn: ~(d | hp) | hn)
+    b.SUBBZ(RUN)                        # - the HN bit that left the last column
+    b.MINU(BEST, BEST, RUN)
+    return b
+
+
+def semi_align(peq: np.ndarray, slen: int, nw: int):
+    """What the semi-global kernels do to a subject's match masks once per task: right-align the slen columns
+    in nw words and make the unused low columns match everything.  Returns (aligned peq [5][nw][n], VP init
+    per word [nw] — 0 in the unused columns, 1 in the subject's)."""
+    s = 32 * nw - slen
+    assert s >= 0
+    n = peq.shape[2]
+    out = np.zeros((5, nw, n), dtype=np.uint32)
+    vp = []
+    for w in range(nw):
+        lo_col = 32 * w - s                    # source column of bit 0 of aligned word w
+        word = np.zeros((5, n), dtype=np.uint64)
+        for src in (lo_col // 32, lo_col // 32 + 1):
+            if 0 <= src < peq.shape[1]:
+                shift = 32 * src - lo_col      # where source word `src` starts within the aligned word
+                v = peq[:, src].astype(np.uint64)
+                word |= (v << np.uint64(shift)) if shift >= 0 else (v >> np.uint64(-shift))
+        dummy = 0xFFFFFFFF if 32 * (w + 1) <= s else ((1 << (s - 32 * w)) - 1 if 32 * w < s else 0)
+        out[:, w] = ((word & np.uint64(0xFFFFFFFF)) | np.uint64(dummy)).astype(np.uint32)
+        vp.append(np.uint32(~dummy & 0xFFFFFFFF))
+    return out, vp
+
+
+def myers_semi_simulate(subjects: np.ndarray, query: np.ndarray, nw: int) -> np.ndarray:
+    """One query against the subjects with myers_semi_body, set up as myers_global_asm_kernel<NW, SEMI> does."""
+    n, slen = subjects.shape
+    peq, vp0 = semi_align(build_peq32(subjects, (slen + 31) // 32), slen, nw)
+    st = []
+    for w in range(nw):
+        st += [np.full(n, vp0[w], np.uint32), np.zeros(n, np.uint32)]
+    st += [np.full(n, slen, np.uint32), np.full(n, slen, np.uint32)]     # D[0][n] = n
+    body = myers_semi_body(nw)
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+    for ch in query:
+        c = code.get(int(ch), 0)
+        body.simulate(st, [peq[c, w] for w in range(nw)])
+    return (-st[2 * nw + 1].astype(np.int64)).astype(np.int16)
 
 
 def myers_planes_body(nw: int) -> Body:

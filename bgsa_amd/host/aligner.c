@@ -395,7 +395,8 @@ int main(int argc, char **argv)
     CK(bgsa_hip_malloc_host(&h_rows, rows_bytes));
     for (int d = 0; d < n_dev; d++) {
         device_t *v = &dev[d];
-        const int64_t cap = v->count + 2 * HIP_V_NUM; /* rounding moves at most two groups between buckets */
+        /* rounding moves at most two groups between buckets; with -D a slice can grow to the whole bucket */
+        const int64_t cap = dynamic ? max_reads : v->count + 2 * HIP_V_NUM;
         CK(bgsa_hip_set_device(v->gpu));
         CK(bgsa_hip_malloc(&v->d_rows, (size_t)(cap * row)));
         CK(bgsa_hip_malloc(&v->d_peq, bgsa_hip_group_words(algo, word_num, threshold) * sizeof(hip_read_t) * (size_t)(cap / HIP_V_NUM)));
@@ -465,6 +466,18 @@ int main(int argc, char **argv)
             CK(bgsa_hip_stream_synchronize(dev[d].stream[0]));
         }
         mem_time += now() - t0;
+        if (b == 0 && dynamic) { /* first launches load code objects: keep that out of the device times -D balances on */
+            for (int d = 0; d < n_dev; d++) {
+                device_t *v = &dev[d];
+                if (!v->count) continue;
+                CK(bgsa_hip_set_device(v->gpu));
+                for (int s = 0; s < 2; s++) {
+                    CK(bgsa_hip_cal_align_score_dev(algo, (const char *)v->d_q, (const hip_read_t *)v->d_peq, v->d_out[s], ref_len,
+                                                    read_len, v->count, 0, 1, word_num, threshold, v->d_work[s], work_bytes, v->stream[s]));
+                    CK(bgsa_hip_stream_synchronize(v->stream[s]));
+                }
+            }
+        }
         if (b + 1 < bucket_num) { /* the rows are in HBM now: the host buffer is free for the next bucket */
             job.want = total_reads - (int64_t)(b + 1) * per_bucket;
             if (job.want > per_bucket) job.want = per_bucket;

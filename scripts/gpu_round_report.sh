@@ -10,11 +10,11 @@ mkdir -p $out
 export TMPDIR=/tmp
 has() { case " $parts " in *" $1 "*) return 0;; *) return 1;; esac; }
 # a step that had to be killed says something about the GPU: stop, do not start the next one
-guard() { if [ "$1" = 124 ] || [ "$1" = 137 ]; then echo "step killed (rc=$1): stopping" | tee -a $out/summary.txt; exit 1; fi; }
+guard() { if [ "$1" = 124 ] || [ "$1" = 137 ]; then echo "step killed (rc=$1): stopping" >> $out/summary.txt; exit 1; fi; }
 step() { # step <name> <seconds> <cmd...>  -> runs under timeout, logs rc
   local name=$1 secs=$2; shift 2
   timeout -k 10 $secs "$@"; local rc=$?
-  echo "$name rc=$rc" | tee -a $out/summary.txt; guard $rc
+  echo "$name rc=$rc" >> $out/summary.txt; echo "$name rc=$rc" >&2; guard $rc
 }
 if has tests; then
   step pytest 1000 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1

@@ -633,7 +633,8 @@ def test_myers_positive_distance(oracle, slen):
 
 
 # ---- semi-global Myers (generator -m 0 -s): the subject end to end inside the query --------------------
-@pytest.mark.parametrize("qlen,slen", [(200, 60), (150, 150), (33, 97), (1, 1), (500, 250), (1000, 300), (700, 1000), (300, 1024)])
+@pytest.mark.parametrize("qlen,slen", [(200, 60), (150, 150), (33, 97), (1, 1), (500, 250), (1000, 300), (700, 1000), (300, 1024),
+                                       (64, 32), (90, 33), (400, 768), (400, 769), (900, 800), (1300, 1100), (3000, 2500), (200, 4000)])
 def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
     q = oracle.gen_reads(600 + qlen, 4, qlen)
     s = oracle.gen_reads(700 + slen, 130, slen)
@@ -650,9 +651,18 @@ def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
     assert np.array_equal(B.align_all_pairs(q[:1], s, algo=B.ALGO_MYERS), oracle.myers64(q[:1], s))
 
 
-def test_myers_semiglobal_beyond_1024_is_refused(oracle):
-    with pytest.raises(B.BgsaHipError, match="1024"):
-        B.align_all_pairs(oracle.gen_reads(1, 2, 100), oracle.gen_reads(2, 64, 1100), algo=B.ALGO_MYERS, semi_global=True)
+def test_myers_semiglobal_kernel_families(oracle):
+    # generated-asm kernels: resident Peq planes up to 768 bp, column blocks of the same body beyond — any length
+    L = B.lib()
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.bgsa_hip_select_alignment(1)
+    try:
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 5).startswith(b"myers_semi_asm_kernel<5>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 24).startswith(b"myers_semi_asm_kernel<24>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 32).startswith(b"myers_blocked_kernel<16, true, true>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 125).startswith(b"myers_blocked_kernel<18, true, true>")
+    finally:
+        L.bgsa_hip_select_alignment(0)
 
 
 # ---- BASELINE.json configs[0] on the GPU: 1k x 1k x 150 bp against the reference binary run live ------
@@ -758,6 +768,9 @@ for slen in (150, 310, 700, 1100, 2300):
 qb = O.gen_reads(904, 3, 150); sb = O.gen_reads(905, 130, 150); sb[:10] = O.mutate(qb[np.arange(10) % 3], np.arange(10), 906)
 for k in (8, 31):
     assert np.array_equal(B.align_all_pairs(qb, sb, algo=B.ALGO_BANDED, k=k), O.banded64(qb, sb, k)), ("banded", k)
+for slen in (150, 700):   # semi-global Myers: asm kernels by default, the compiler-scheduled one under BGSA_MYERS_IMPL=c
+    s = O.gen_reads(907 + slen, 70, slen)
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS, semi_global=True), O.dp_edit_semiglobal(q, s)), ("semi", slen)
 print("knobs ok")
 """
 

@@ -39,6 +39,24 @@ def test_myers_body_matches_oracle(oracle, qlen, slen):
         assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
 
 
+@pytest.mark.parametrize("qlen,slen,nw", [(200, 60, 2), (150, 150, 5), (33, 97, 4), (1, 1, 1), (120, 64, 2), (300, 250, 8),
+                                         (90, 257, 10), (150, 140, 5), (64, 32, 1), (40, 33, 2), (500, 300, 12)])
+def test_myers_semi_body_matches_the_dp(oracle, qlen, slen, nw):
+    """Semi-global Myers (generator -s): right-aligned subject, carry-in 0, running last-column score from
+    the chains' final carries — against the textbook DP (subject end to end inside the query)."""
+    q = oracle.gen_reads(2500 + qlen, 3, qlen)
+    s = oracle.gen_reads(2600 + slen, 40, slen)
+    if qlen >= slen:
+        for r in range(12):
+            off = (r * 17) % (qlen - slen + 1)
+            s[r] = oracle.mutate(q[r % 3: r % 3 + 1, off:off + slen], [r % 6], 2700 + r)[0]
+    s[3, : slen // 2] = ord("N")
+    want = oracle.dp_edit_semiglobal(q, s)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.myers_semi_simulate(s, q[i], nw), want[i])
+    assert R.count_hazard_nops(R.myers_semi_body(nw)) <= 2      # two wait states per row, of 10 nw + 3 instructions
+
+
 @pytest.mark.parametrize("qlen,slen", [(300, 300), (150, 150), (90, 257)])
 def test_myers_planes_body_matches_oracle(oracle, qlen, slen):
     q, s = _inputs(oracle, 1500 + slen, 2, 40, qlen, slen)
