@@ -231,13 +231,18 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
 // HP / HN shift chains drop D[i][n] - D[i-1][n] out as their final carries; the s = 32 * total_words - n unused
 // low columns match every character and start at VP = 0, which keeps them at D = 0 — the row edge of the mode,
 // delivered to the first real column.
-// Aligned word `aw` of class plane `row` (source words row[0 .. word_num), stride kLanes), s = 32 q + r:
-__device__ __forceinline__ uint32_t semi_aligned_word(const uint32_t *row, int word_num, int aw, int q, int r)
+// Source word `i` of class plane `row` (words row[0 .. word_num), stride kLanes), zero outside the subject.
+// Unconditional load, index clamped and result masked: a guarded load becomes a branch per word and the
+// loads of a block then complete one after the other instead of together.
+__device__ __forceinline__ uint32_t semi_source_word(const uint32_t *row, int word_num, int i)
 {
-    const int hi = aw - q, lo = aw - q - 1;
-    const uint32_t a = (hi >= 0 && hi < word_num) ? row[hi * kLanes] : 0u;
-    const uint32_t b = (r != 0 && lo >= 0 && lo < word_num) ? row[lo * kLanes] : 0u;
-    return r ? ((a << r) | (b >> (32 - r))) : a;
+    const int ic = i < 0 ? 0 : (i >= word_num ? word_num - 1 : i);
+    return row[ic * kLanes] & ((i >= 0 && i < word_num) ? ~0u : 0u);
+}
+// Aligned word from its two source words, s = 32 q + r: hi = source word aw - q, lo = source word aw - q - 1.
+__device__ __forceinline__ uint32_t semi_funnel(uint32_t hi, uint32_t lo, int r)
+{
+    return r ? __builtin_amdgcn_alignbit(hi, lo, 32 - r) : hi;
 }
 // the unused low columns of aligned word aw (wave-uniform)
 __device__ __forceinline__ uint32_t semi_dummy_mask(int aw, int s)
@@ -262,10 +267,14 @@ __global__ __launch_bounds__(256) void myers_semi_asm_kernel(
     uint32_t P[kChars][NW];
     const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
 #pragma unroll
-    for (int c = 0; c < kChars; c++)
+    for (int c = 0; c < kChars; c++) {
+        const uint32_t *row = g + static_cast<size_t>(c) * word_num * kLanes;
+        uint32_t src[NW + 1];
 #pragma unroll
-        for (int w = 0; w < NW; w++)
-            P[c][w] = semi_aligned_word(g + static_cast<size_t>(c) * word_num * kLanes, word_num, w, sq, sr) | semi_dummy_mask(w, s_cols);
+        for (int w = 0; w <= NW; w++) src[w] = semi_source_word(row, word_num, w - sq - 1);
+#pragma unroll
+        for (int w = 0; w < NW; w++) P[c][w] = semi_funnel(src[w + 1], src[w], sr) | semi_dummy_mask(w, s_cols);
+    }
 
     const int q0 = blockIdx.y * q_tile;
     const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
@@ -385,29 +394,36 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
             for (int blk = 0; blk < n_blocks; blk++) {
                 uint32_t Bp[PEQ ? 1 : 3 * NW];       // 3-bit character-code planes of the block, or
                 uint32_t Pq[kChars][PEQ ? NW : 1];   // its five Peq planes (PEQ: 10 VALU per word, narrower blocks)
-#pragma unroll
-                for (int w = 0; w < NW; w++) {
-                    const int gw = blk * NW + w;
-                    uint32_t p[kChars];
-                    // unconditional loads (index clamped, result masked): a guarded load becomes a branch per
-                    // word, and this runs per query and block, not once per task as in the plain kernels
-                    const int gwc = gw < word_num ? gw : word_num - 1;
-                    const uint32_t keep = gw < word_num ? ~0u : 0u;
+                if constexpr (SEMI) {
 #pragma unroll
                     for (int c = 0; c < kChars; c++) {
-                        if constexpr (SEMI)
-                            p[c] = semi_aligned_word(g + static_cast<size_t>(c) * word_num * kLanes, word_num, gw, sq, sr) |
-                                   semi_dummy_mask(gw, s_cols);
-                        else
-                            p[c] = g[(c * word_num + gwc) * kLanes] & keep;
-                    }
-                    if constexpr (PEQ) {
+                        const uint32_t *row = g + static_cast<size_t>(c) * word_num * kLanes;
+                        uint32_t src[NW + 1];
 #pragma unroll
-                        for (int c = 0; c < kChars; c++) Pq[c][w] = p[c];
-                    } else {
-                        Bp[3 * w + 0] = p[1] | p[3];
-                        Bp[3 * w + 1] = p[2] | p[3];
-                        Bp[3 * w + 2] = p[4];
+                        for (int w = 0; w <= NW; w++) src[w] = semi_source_word(row, word_num, blk * NW + w - sq - 1);
+#pragma unroll
+                        for (int w = 0; w < NW; w++)
+                            Pq[c][w] = semi_funnel(src[w + 1], src[w], sr) | semi_dummy_mask(blk * NW + w, s_cols);
+                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const int gw = blk * NW + w;
+                        uint32_t p[kChars];
+                        // unconditional loads (index clamped, result masked): a guarded load becomes a branch per
+                        // word, and this runs per query and block, not once per task as in the plain kernels
+                        const int gwc = gw < word_num ? gw : word_num - 1;
+                        const uint32_t keep = gw < word_num ? ~0u : 0u;
+#pragma unroll
+                        for (int c = 0; c < kChars; c++) p[c] = g[(c * word_num + gwc) * kLanes] & keep;
+                        if constexpr (PEQ) {
+#pragma unroll
+                            for (int c = 0; c < kChars; c++) Pq[c][w] = p[c];
+                        } else {
+                            Bp[3 * w + 0] = p[1] | p[3];
+                            Bp[3 * w + 1] = p[2] | p[3];
+                            Bp[3 * w + 2] = p[4];
+                        }
                     }
                 }
                 uint32_t st[2 * NW + 6];
