@@ -93,6 +93,7 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_bucket_release.argtypes = [vp]
     u64p = ctypes.POINTER(ctypes.c_uint64)
     L.bgsa_hip_seam_stats.argtypes = [u64p, u64p, u64p]
+    L.bgsa_hip_row_cache_stats.argtypes = [u64p, u64p]
     L.bgsa_hip_event_create.argtypes = [ctypes.POINTER(vp)]
     L.bgsa_hip_event_destroy.argtypes = [vp]
     L.bgsa_hip_event_record.argtypes = [vp, vp]

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -710,6 +711,7 @@ struct ResidentRange {
     void *dev = nullptr;                   // device mirror (nullptr: not uploaded yet)
     int device = -1;
     bool uploaded = false;
+    uint64_t gen = 0;                      // identity of this content: a rewritten range gets a new one
 };
 
 // 32-bit words per (class, lane) of a HOST Peq buffer whose caller passed `word_num`, or -1.  Myers and
@@ -742,11 +744,29 @@ static int upload_peq(void *dev, const void *host, size_t groups, int w_host, in
     return BGSA_HIP_OK;
 }
 
+// align_hip's row cache.  The reference's grid calls align_<arch> once per (query, chunk of ~27 groups)
+// (cal_cpu.c:63-84): 57,900 calls per 100-query block of a 1M-subject bucket, each a launch + two copies if
+// taken literally.  With the bucket resident, the first call for a query scores it against the WHOLE bucket in
+// one launch and keeps the row on the host; the other 578 calls for that query are a memcpy of their chunk.
+// A row is identified by the bucket's content id, the query's bytes and the scoring parameters.
+struct CachedRow {
+    uint64_t range_gen = 0;
+    bgsa_hip_params_t params{};
+    int read_len = 0;
+    std::string query;                                         // the mapped query row, ref_len bytes
+    std::shared_ptr<std::vector<unsigned char>> scores;        // [subjects of the range] x element size
+    uint64_t stamp = 0;
+};
+
 struct HostSeam {
     hipStream_t stream = nullptr;
     int device = -1;
-    void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr;
-    size_t cap_content = 0, cap_peq = 0, cap_results = 0;
+    void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr, *d_rowq = nullptr;
+    size_t cap_content = 0, cap_peq = 0, cap_results = 0, cap_rowq = 0;
+    std::vector<CachedRow> rows;
+    uint64_t next_gen = 1, clock = 0, row_hits = 0, row_misses = 0;
+    size_t row_bytes = 0;
+    static constexpr size_t kRowCacheBytes = 1u << 30;
     std::vector<unsigned char> content_copy;   // what d_content holds
     std::vector<ResidentRange> ranges;
     bool auto_resident = true;
@@ -771,6 +791,14 @@ static void drop_overlapping(const unsigned char *lo, size_t bytes)  // g_seam h
         ResidentRange &r = g_host.ranges[i];
         if (lo < r.host + r.bytes && r.host < lo + bytes) {
             if (r.dev) (void)hipFree(r.dev);
+            for (size_t j = 0; j < g_host.rows.size();) {      // its cached rows go with it
+                if (g_host.rows[j].range_gen == r.gen) {
+                    g_host.row_bytes -= g_host.rows[j].scores->size();
+                    g_host.rows.erase(g_host.rows.begin() + j);
+                } else {
+                    j++;
+                }
+            }
             g_host.ranges.erase(g_host.ranges.begin() + i);
         } else {
             i++;
@@ -787,11 +815,11 @@ static int seam_stream()  // g_seam held
         (void)hipStreamSynchronize(g_host.stream);
         (void)hipStreamDestroy(g_host.stream);
         g_host.stream = nullptr;
-        for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results}) {
+        for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results, &g_host.d_rowq}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
-        g_host.cap_content = g_host.cap_peq = g_host.cap_results = 0;
+        g_host.cap_content = g_host.cap_peq = g_host.cap_results = g_host.cap_rowq = 0;
         g_host.content_copy.clear();
         for (ResidentRange &r : g_host.ranges) {
             if (r.dev) (void)hipFree(r.dev);
@@ -802,6 +830,33 @@ static int seam_stream()  // g_seam held
     BGSA_HIP_TRY(hipStreamCreateWithFlags(&g_host.stream, hipStreamNonBlocking));
     g_host.device = dev;
     return BGSA_HIP_OK;
+}
+
+// The resident range that holds `bytes` at `peq_host` in this layout, uploaded; nullptr if there is none.
+static ResidentRange *resident_range(const unsigned char *peq_host, size_t bytes, int w_host, int w_dev, hipStream_t s)  // g_seam held
+{
+    const size_t host_group_bytes = static_cast<size_t>(BGSA_CHAR_NUM) * w_host * 256;
+    const size_t dev_group_bytes = static_cast<size_t>(BGSA_CHAR_NUM) * w_dev * 256;
+    for (ResidentRange &r : g_host.ranges) {
+        if (peq_host < r.host || peq_host + bytes > r.host + r.bytes || r.w_host != w_host || r.w_dev != w_dev ||
+            (peq_host - r.host) % host_group_bytes != 0)
+            continue;
+        if (!r.uploaded || r.device != g_host.device) {
+            const size_t r_groups = r.bytes / host_group_bytes;
+            if (r.dev && r.device != g_host.device) { (void)hipFree(r.dev); r.dev = nullptr; }
+            if (!r.dev && hipMalloc(&r.dev, r_groups * dev_group_bytes) != hipSuccess) {
+                set_error_text("hipMalloc (resident bucket) failed");
+                die("resident bucket");
+            }
+            if (upload_peq(r.dev, r.host, r_groups, w_host, w_dev, s)) die("resident bucket");
+            r.device = g_host.device;
+            r.uploaded = true;
+            g_host.peq_uploads++;
+            g_host.peq_upload_bytes += r.bytes;
+        }
+        return &r;
+    }
+    return nullptr;
 }
 
 int bgsa_hip_set_auto_resident(int on)
@@ -824,6 +879,7 @@ int bgsa_hip_bucket_resident(const hip_read_t *host_peq, size_t bytes, int word_
     r.host = lo;
     r.bytes = bytes;
     r.w_host = r.w_dev = word_num;   // the library's own layout
+    r.gen = g_host.next_gen++;
     g_host.ranges.push_back(r);
     return BGSA_HIP_OK;
 }
@@ -849,16 +905,24 @@ int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_up
     return BGSA_HIP_OK;
 }
 
+int bgsa_hip_row_cache_stats(uint64_t *hits, uint64_t *misses)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    if (hits) *hits = g_host.row_hits;
+    if (misses) *misses = g_host.row_misses;
+    return BGSA_HIP_OK;
+}
+
 int bgsa_hip_release_workspace(void)
 {
     {
         std::lock_guard<std::mutex> turn(g_seam);
         if (g_host.stream) (void)hipStreamSynchronize(g_host.stream);
-        for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results}) {
+        for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results, &g_host.d_rowq}) {
             if (*p) BGSA_HIP_TRY(hipFree(*p));
             *p = nullptr;
         }
-        g_host.cap_content = g_host.cap_peq = g_host.cap_results = 0;
+        g_host.cap_content = g_host.cap_peq = g_host.cap_results = g_host.cap_rowq = 0;
         g_host.content_copy.clear();
         drop_overlapping(nullptr, ~static_cast<size_t>(0));
     }
@@ -903,6 +967,7 @@ void hip_handle_reads(seq_t *read_seq, hip_read_t *result_reads, int word_num, i
         r.bytes = bytes;
         r.w_host = w_host;
         r.w_dev = bgsa_hip_word_num(algo, len, len, k);
+        r.gen = g_host.next_gen++;
         g_host.ranges.push_back(r);
     }
 }
@@ -950,27 +1015,9 @@ void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_
     // Peq: a resident range, or the per-call mirror
     const unsigned char *peq_host = reinterpret_cast<const unsigned char *>(preprocess_reads);
     const hip_read_t *d_peq = nullptr;
-    for (ResidentRange &r : g_host.ranges) {
-        if (peq_host < r.host || peq_host + peq_bytes > r.host + r.bytes || r.w_host != w_host || r.w_dev != w_dev ||
-            (peq_host - r.host) % host_group_bytes != 0)
-            continue;
-        if (!r.uploaded || r.device != g_host.device) {
-            const size_t r_groups = r.bytes / host_group_bytes;
-            if (r.dev && r.device != g_host.device) { (void)hipFree(r.dev); r.dev = nullptr; }
-            if (!r.dev && hipMalloc(&r.dev, r_groups * dev_group_bytes) != hipSuccess) {
-                set_error_text("hipMalloc (resident bucket) failed");
-                die("hip_cal_align_score");
-            }
-            if (upload_peq(r.dev, r.host, r_groups, w_host, w_dev, s)) die("hip_cal_align_score");
-            r.device = g_host.device;
-            r.uploaded = true;
-            g_host.peq_uploads++;
-            g_host.peq_upload_bytes += r.bytes;
-        }
-        d_peq = reinterpret_cast<const hip_read_t *>(static_cast<unsigned char *>(r.dev) +
-                                                     (peq_host - r.host) / host_group_bytes * dev_group_bytes);
-        break;
-    }
+    if (ResidentRange *r = resident_range(peq_host, peq_bytes, w_host, w_dev, s))
+        d_peq = reinterpret_cast<const hip_read_t *>(static_cast<unsigned char *>(r->dev) +
+                                                     (peq_host - r->host) / host_group_bytes * dev_group_bytes);
     if (!d_peq) {
         if (g_host.reserve(&g_host.d_peq, &g_host.cap_peq, groups * dev_group_bytes)) die("hip_cal_align_score");
         if (upload_peq(g_host.d_peq, preprocess_reads, groups, w_host, w_dev, s)) die("hip_cal_align_score");
@@ -995,6 +1042,76 @@ void hip_cal_align_score(char *content, hip_read_t *preprocess_reads, hip_write_
 void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_num,
                int chunk_read_num, int result_index, hip_write_t *results, hip_data_t *dvdh_bit_mem)
 {
+    // One query against chunk_read_num groups; results land at results[result_index * HIP_V_NUM ...]
+    // (reference original/BGSA_CPU/align_core.c:138-145).  With the chunk inside a resident bucket the query is
+    // scored against the whole bucket once and every call copies its chunk out of that row (CachedRow above).
+    if (chunk_read_num > 0 && ref && read && results && ref_len > 0) {
+        std::unique_lock<std::mutex> turn(g_seam);
+        bgsa_hip_params_t params;
+        bgsa_hip_current_params(&params);
+        const size_t esz = result_elem_size(params.algo);
+        const int w_host = host_words32(params.algo, read_len, params.k, word_num);
+        if (w_host > 0 && g_host.auto_resident && seam_stream() == BGSA_HIP_OK) {
+            const int w_dev = bgsa_hip_word_num(params.algo, ref_len, read_len, params.k);
+            const size_t host_group_bytes = static_cast<size_t>(BGSA_CHAR_NUM) * w_host * 256;
+            const unsigned char *peq_host = reinterpret_cast<const unsigned char *>(read);
+            ResidentRange *r = resident_range(peq_host, host_group_bytes * chunk_read_num, w_host, w_dev, g_host.stream);
+            if (r) {
+                g_host.calls++;
+                const size_t r_groups = r->bytes / host_group_bytes, first_group = (peq_host - r->host) / host_group_bytes;
+                std::shared_ptr<std::vector<unsigned char>> row;
+                for (CachedRow &c : g_host.rows)
+                    if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
+                        memcmp(&c.params, &params, sizeof params) == 0 && memcmp(c.query.data(), ref, ref_len) == 0) {
+                        c.stamp = ++g_host.clock;
+                        row = c.scores;
+                        g_host.row_hits++;
+                        break;
+                    }
+                if (!row) {
+                    g_host.row_misses++;
+                    hipStream_t s = g_host.stream;
+                    const size_t n_sub = r_groups * HIP_V_NUM;
+                    if (g_host.reserve(&g_host.d_rowq, &g_host.cap_rowq, static_cast<size_t>(ref_len) + 16) ||
+                        g_host.reserve(&g_host.d_results, &g_host.cap_results, n_sub * esz))
+                        die("align_hip");
+                    std::string qrow(ref, ref + ref_len);
+                    qrow.push_back('\n');
+                    row = std::make_shared<std::vector<unsigned char>>(n_sub * esz);
+                    if (hipMemcpyAsync(g_host.d_rowq, qrow.data(), qrow.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+                        bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_rowq),
+                                                    static_cast<const hip_read_t *>(r->dev), g_host.d_results, ref_len, read_len,
+                                                    static_cast<int64_t>(n_sub), 0, 1, w_dev, nullptr, 0, s) != BGSA_HIP_OK ||
+                        hipMemcpyAsync(row->data(), g_host.d_results, n_sub * esz, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                        hipStreamSynchronize(s) != hipSuccess) {
+                        if (g_last_error.empty()) set_error_text("align_hip: scoring the query row failed");
+                        die("align_hip");
+                    }
+                    if (bgsa_hip_stream_faults(1) != 0) die("align_hip");
+                    while (!g_host.rows.empty() && g_host.row_bytes + row->size() > HostSeam::kRowCacheBytes) {
+                        size_t oldest = 0;
+                        for (size_t j = 1; j < g_host.rows.size(); j++)
+                            if (g_host.rows[j].stamp < g_host.rows[oldest].stamp) oldest = j;
+                        g_host.row_bytes -= g_host.rows[oldest].scores->size();
+                        g_host.rows.erase(g_host.rows.begin() + oldest);
+                    }
+                    CachedRow c;
+                    c.range_gen = r->gen;
+                    c.params = params;
+                    c.read_len = read_len;
+                    c.query.assign(ref, ref + ref_len);
+                    c.scores = row;
+                    c.stamp = ++g_host.clock;
+                    g_host.row_bytes += row->size();
+                    g_host.rows.push_back(std::move(c));
+                }
+                turn.unlock();   // the copy needs no lock: the row is shared, immutable
+                memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
+                       row->data() + first_group * HIP_V_NUM * esz, static_cast<size_t>(chunk_read_num) * HIP_V_NUM * esz);
+                return;
+            }
+        }
+    }
     // One query against chunk_read_num groups: the coarse call with a 1-row query buffer and the
     // chunk as the whole bucket; results land at results[result_index * HIP_V_NUM ...]
     // (reference original/BGSA_CPU/align_core.c:138-145).

@@ -163,6 +163,12 @@ int bgsa_hip_bucket_resident(const hip_read_t *host_peq, size_t bytes, int word_
 int bgsa_hip_bucket_release(const hip_read_t *host_peq);   /* NULL: all of them */
 /* Counters of the seams since process start (any pointer may be NULL). */
 int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_upload_bytes);
+/* align_hip's row cache: the reference's grid calls align_<arch> once per (query, chunk of ~27 groups)
+ * (cal_cpu.c:63-84).  With the chunk inside a resident bucket, the first call for a query scores it
+ * against the whole bucket in one launch and keeps that row (host memory, at most 1 GiB of rows, least
+ * recently used first out); the other calls for the same query, bucket and parameters copy their chunk
+ * out of it.  hits / misses since process start. */
+int bgsa_hip_row_cache_stats(uint64_t *hits, uint64_t *misses);
 
 /* ASCII rows -> Peq blocks, layout [group][char 0..4][word][lane 0..63]
  * (replaces cpu_handle_reads, reference original/BGSA_CPU/global.c:25-70; for BGSA_ALGO_BANDED

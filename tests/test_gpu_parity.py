@@ -476,6 +476,49 @@ def test_host_seam_keeps_the_bucket_resident(oracle):
         L.bgsa_hip_bucket_release(None)
 
 
+def test_align_hip_grid_uses_the_row_cache(oracle):
+    """The reference's grid (cal_cpu.c:63-84) through align_hip: every (query, chunk) pair is a call; with the
+    bucket resident each query is scored once against the whole bucket and the other calls copy their chunk."""
+    L = B.lib()
+    q = oracle.gen_reads(71, 6, 150)
+    s, _ = B.pad_rows(oracle.gen_reads(72, 64 * 7, 150))
+    s[:6] = oracle.mutate(q, np.arange(6), 73)
+    want = oracle.myers64(q, s)
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.init_mapping_table()
+    sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+    wn, n = 5, s.shape[0]
+    gw = B.group_words(B.ALGO_MYERS, wn)
+    peq = np.zeros(gw * (n // 64), dtype=np.uint32)
+    L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+
+    def stats():
+        h, m = ctypes.c_uint64(), ctypes.c_uint64()
+        L.bgsa_hip_row_cache_stats(ctypes.byref(h), ctypes.byref(m))
+        return h.value, m.value
+
+    h0, m0 = stats()
+    out = np.zeros((6, n), dtype=np.int16)
+    chunk = 3                                              # 7 groups in chunks of 3, 3, 1 (cal_cpu.c:56-62)
+    for i in range(6):
+        row = np.ascontiguousarray(qmapped[i * 151:(i + 1) * 151])
+        for j in range(0, 7, chunk):
+            c = min(chunk, 7 - j)
+            L.align_hip(row.ctypes.data, peq[gw * j:].ctypes.data, 150, 150, wn, c, i * 7 + j, out.ctypes.data, None)
+    assert np.array_equal(out, want)
+    h1, m1 = stats()
+    assert m1 - m0 == 6 and h1 - h0 == 6 * 2               # one launch per query, two more calls served from its row
+    # a rewritten bucket drops its rows: same query, new subjects
+    s2, _ = B.pad_rows(oracle.gen_reads(74, 64 * 7, 150))
+    sbuf2, seq2, _ = _host_seam_inputs(L, q, s2)
+    peq[:] = 0
+    L.hip_handle_reads(ctypes.byref(seq2), peq.ctypes.data, wn, 0, n)
+    res = np.zeros(n, dtype=np.int16)
+    L.align_hip(np.ascontiguousarray(qmapped[:151]).ctypes.data, peq.ctypes.data, 150, 150, wn, 7, 0, res.ctypes.data, None)
+    assert np.array_equal(res, oracle.myers64(q[:1], s2)[0]) and stats()[1] == m1 + 1
+    L.bgsa_hip_bucket_release(None)
+
+
 def test_wrong_word_num_is_refused(oracle):
     # the kernels index the blocks with the caller's word_num: anything but the layout's own value is an error
     import torch
