@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -765,6 +766,8 @@ struct HostSeam {
     void *d_content = nullptr, *d_peq = nullptr, *d_results = nullptr, *d_rowq = nullptr;
     size_t cap_content = 0, cap_peq = 0, cap_results = 0, cap_rowq = 0;
     std::vector<CachedRow> rows;
+    void *h_stage = nullptr;           // page-locked landing buffer of a row (copies to pageable memory are far slower)
+    size_t cap_stage = 0;
     uint64_t next_gen = 1, clock = 0, row_hits = 0, row_misses = 0;
     size_t row_bytes = 0;
     static constexpr size_t kRowCacheBytes = 1u << 30;
@@ -908,6 +911,31 @@ int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_up
     if (peq_uploads) *peq_uploads = g_host.peq_uploads;
     if (peq_upload_bytes) *peq_upload_bytes = g_host.peq_upload_bytes;
     return BGSA_HIP_OK;
+}
+
+// BGSA_HIP_SEAM_STATS=1: print the counters of the host seams when the process ends (what the unmodified
+// reference pipeline did with the library: calls, bucket uploads, row-cache hits and misses, time in them).
+static std::atomic<uint64_t> g_row_ns{0}, g_lock_wait_ns{0};
+static void print_seam_stats()
+{
+    fprintf(stderr, "[bgsa_hip] seam calls %llu, Peq uploads %llu (%.1f MB), align_hip rows computed %llu in %.3f s, served from a row: "
+                    "%llu under the lock + %llu from the caller's last row; waited for the seam lock %.3f s\n",
+            (unsigned long long)g_host.calls, (unsigned long long)g_host.peq_uploads, g_host.peq_upload_bytes / 1e6,
+            (unsigned long long)g_host.row_misses, g_row_ns.load() / 1e9, (unsigned long long)g_host.row_hits,
+            (unsigned long long)g_row_fast_hits.load(), g_lock_wait_ns.load() / 1e9);
+}
+static void seam_stats_at_exit()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("BGSA_HIP_SEAM_STATS");
+        if (e && e[0] == '1') atexit(print_seam_stats);
+    });
+}
+static inline uint64_t now_ns()
+{
+    return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
+        std::chrono::steady_clock::now().time_since_epoch()).count());
 }
 
 int bgsa_hip_row_cache_stats(uint64_t *hits, uint64_t *misses)
@@ -1081,7 +1109,10 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 return;
             }
         }
+        seam_stats_at_exit();
+        const uint64_t t_lock = now_ns();
         std::unique_lock<std::mutex> turn(g_seam);
+        g_lock_wait_ns.fetch_add(now_ns() - t_lock, std::memory_order_relaxed);
         const size_t esz = result_elem_size(params.algo);
         const int w_host = host_words32(params.algo, read_len, params.k, word_num);
         if (w_host > 0 && g_host.auto_resident && seam_stream() == BGSA_HIP_OK) {
@@ -1103,6 +1134,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                     }
                 if (!row) {
                     g_host.row_misses++;
+                    const uint64_t t_row = now_ns();
                     hipStream_t s = g_host.stream;
                     const size_t n_sub = r_groups * HIP_V_NUM;
                     if (g_host.reserve(&g_host.d_rowq, &g_host.cap_rowq, static_cast<size_t>(ref_len) + 16) ||
@@ -1110,16 +1142,27 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                         die("align_hip");
                     std::string qrow(ref, ref + ref_len);
                     qrow.push_back('\n');
-                    row = std::make_shared<std::vector<unsigned char>>(n_sub * esz);
+                    if (g_host.cap_stage < n_sub * esz) {
+                        if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
+                        g_host.h_stage = nullptr;
+                        g_host.cap_stage = 0;
+                        if (hipHostMalloc(&g_host.h_stage, n_sub * esz, hipHostMallocPortable) != hipSuccess) {
+                            set_error_text("align_hip: hipHostMalloc (row staging) failed");
+                            die("align_hip");
+                        }
+                        g_host.cap_stage = n_sub * esz;
+                    }
                     if (hipMemcpyAsync(g_host.d_rowq, qrow.data(), qrow.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
                         bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_rowq),
                                                     static_cast<const hip_read_t *>(r->dev), g_host.d_results, ref_len, read_len,
                                                     static_cast<int64_t>(n_sub), 0, 1, w_dev, nullptr, 0, s) != BGSA_HIP_OK ||
-                        hipMemcpyAsync(row->data(), g_host.d_results, n_sub * esz, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                        hipMemcpyAsync(g_host.h_stage, g_host.d_results, n_sub * esz, hipMemcpyDeviceToHost, s) != hipSuccess ||
                         hipStreamSynchronize(s) != hipSuccess) {
                         if (g_last_error.empty()) set_error_text("align_hip: scoring the query row failed");
                         die("align_hip");
                     }
+                    const unsigned char *staged = static_cast<const unsigned char *>(g_host.h_stage);
+                    row = std::make_shared<std::vector<unsigned char>>(staged, staged + n_sub * esz);
                     if (bgsa_hip_stream_faults(1) != 0) die("align_hip");
                     while (!g_host.rows.empty() && g_host.row_bytes + row->size() > HostSeam::kRowCacheBytes) {
                         size_t oldest = 0;
@@ -1137,6 +1180,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                     c.stamp = ++g_host.clock;
                     g_host.row_bytes += row->size();
                     g_host.rows.push_back(std::move(c));
+                    g_row_ns.fetch_add(now_ns() - t_row, std::memory_order_relaxed);
                 }
                 last.epoch = g_range_epoch.load(std::memory_order_acquire);
                 last.range_host = r->host;
