@@ -133,6 +133,10 @@ class ScoreGatherStream:
         self.layout, self.dtype, self.block_rows, self.depth = layout, dtype, int(block_rows), int(depth)
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        # gloo has no point-to-point operations on device tensors: tiles then travel through host memory (the
+        # 2-rank rehearsal of this class on one GPU box; RCCL moves them device to device)
+        self.via_host = self.cuda and dist is not None and dist.get_backend() == "gloo"
+        self.host_parts = {}   # slot -> [(segment view on the device, host tensor)] to copy in once received
         total = sum(self.counts)
         self.offsets = [sum(self.counts[:r]) * self.block_rows for r in range(self.world)]
         if self.rank == 0:
@@ -150,6 +154,8 @@ class ScoreGatherStream:
         for w in self.pending[slot]:
             w.wait()
         self.pending[slot] = []
+        for seg, host in self.host_parts.pop(slot, []):
+            seg.copy_(host.view(seg.dtype).view(seg.shape), non_blocking=False)
         if slot in self.unflushed:
             index, rows = self.unflushed.pop(slot)
             if self.on_block is not None:
@@ -187,7 +193,13 @@ class ScoreGatherStream:
                 seg = lambda r: buf[self.offsets[r] * rows // self.block_rows: self.offsets[r] * rows // self.block_rows + rows * self.counts[r]]
                 seg(0).view(rows, self.counts[0]).copy_(tile, non_blocking=True)
                 for r in range(1, self.world):
-                    if self.counts[r]:
+                    if not self.counts[r]:
+                        continue
+                    if self.via_host:
+                        host = torch.empty(seg(r).numel() * seg(r).element_size(), dtype=torch.uint8)
+                        self.host_parts.setdefault(slot, []).append((seg(r), host))
+                        ops.append(self.dist.P2POp(self.dist.irecv, host, r))
+                    else:
                         ops.append(self.dist.P2POp(self.dist.irecv, seg(r).view(torch.uint8), r))
                 self.last = (slot, rows)
             elif self.counts[self.rank]:
@@ -197,13 +209,16 @@ class ScoreGatherStream:
                         self.staging[slot] = torch.empty((self.block_rows, self.counts[self.rank]), dtype=self.dtype, device=self.device)
                     src = self.staging[slot][:rows]
                     src.copy_(tile, non_blocking=True)
-                ops.append(self.dist.P2POp(self.dist.isend, src.reshape(-1).view(torch.uint8), 0))
+                flat = src.reshape(-1).view(torch.uint8)
+                ops.append(self.dist.P2POp(self.dist.isend, flat.cpu() if self.via_host else flat, 0))
             if ops:
                 self.pending[slot] = self.dist.batch_isend_irecv(ops)
             if self.rank == 0 and self.layout == "row_major":
                 for w in self.pending[slot]:
                     w.wait()
                 self.pending[slot] = []
+                for seg_dev, host in self.host_parts.pop(slot, []):
+                    seg_dev.copy_(host.view(seg_dev.dtype).view(seg_dev.shape), non_blocking=False)
                 col = 0
                 for r in range(self.world):
                     c = self.counts[r]
@@ -263,7 +278,9 @@ class ShardedAligner:
             self._aligner = B.DeviceAligner(self.algo, str(self.device), self.k, self.scores, self.semi_global)
         a = self._aligner
         a.set_queries(queries)
-        a.set_subjects(subjects)
+        if getattr(self, "_resident", None) is not subjects:   # the shard stays in HBM across query blocks
+            a.set_subjects(subjects)
+            self._resident = subjects
         return a.score()[:, : a.ns_real]
 
     # ---- the two exchanges --------------------------------------------------------------------------
