@@ -361,10 +361,20 @@ def main() -> int:
 
     # ---- N > 1: the same steps with the score gather of SURVEY §2a C3 streamed beside them -------------------
     gather_info = None
-    if dist is not None and world > 1:
+    if dist is not None and world > 1 and os.environ.get("BGSA_BENCH_GATHER", "1") != "0":
+        # set-up can only fail locally (allocation): agree on it before anyone enters a transfer the others would wait for
+        all_shards = shards if shards is not None else [type("S", (), {"start": r * ns, "count": ns})() for r in range(world)]
+        gs, setup_error = None, None
         try:
-            all_shards = shards if shards is not None else [type("S", (), {"start": r * ns, "count": ns})() for r in range(world)]
             gs = ScoreGatherStream(dist, dev, [s.count for s in all_shards], aligner.out_dtype, block_rows=REF_BUCKET_COUNT)
+        except Exception as e:
+            setup_error = repr(e)
+        ok = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            gather_info = {"error": setup_error or "set-up failed on another rank"}
+    if gather_info is None and dist is not None and world > 1 and os.environ.get("BGSA_BENCH_GATHER", "1") != "0":
+        try:
             nq_g = min(nq, 10 * REF_BUCKET_COUNT)     # ten reference-sized blocks are enough to see the steady state
 
             def gather_step():
