@@ -42,8 +42,6 @@ def main() -> int:
             k = 0
             hi = 4200 if long_case else 420
             qlen, slen = int(rng.integers(1, hi)), int(rng.integers(1, hi))
-            if kind == "myers_semi":
-                slen = min(slen, 1024)
         nq = int(rng.integers(1, 9 if long_case else 40))
         ns = int(rng.integers(1, 200 if long_case else 700))
         q = O.gen_reads(int(rng.integers(1 << 30)), nq, qlen)
@@ -69,6 +67,10 @@ def main() -> int:
             if kind == "bitpal_factor":
                 f = int(rng.integers(2, 5))
                 scores = tuple(f * x for x in scores)
+                if rng.random() < 0.3:          # a mismatch below two gaps runs as its mismatch = 2*gap instance
+                    scores = (scores[0], min(scores[1], 2 * scores[2]) - int(rng.integers(0, 7)), scores[2])
+                if rng.random() < 0.15:         # edit-distance sets run on the Myers body
+                    scores = (0, -f, -f)
             semi = kind == "bitpal_semi"
             got = B.align_all_pairs(q, s, algo=B.ALGO_BITPAL, scores=scores, semi_global=semi)
             want = (O.dp_semiglobal if semi else O.dp_nw)(q, s, *scores)
