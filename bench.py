@@ -15,7 +15,7 @@ scores stay in HBM.  For N > 1 the driver launches one rank per GPU (torch.distr
     problem is the same at every N.
 
 `value` is the kernel-path rate (the reference's "cal GCUPS", cal_cpu.c:472); beside it the line carries
-`total_gcups` (raw rows on the host -> scores on the host for reference-sized blocks: H2D + GPU
+`total_gcups` (raw rows on the host -> scores on the host, the whole job in reference-sized blocks: H2D + GPU
 preprocess + kernel + D2H, the reference's "Total GCUPS", cal_cpu.c:473-474) and, for N > 1,
 `gather` (the same steps with the per-block score gather to rank 0 over xGMI streamed beside them).
 
@@ -211,11 +211,12 @@ def make_workload(config, algo, nq, ns, length, k, mix, rank, dev, dist):
 
 # ---- Total GCUPS: host rows -> host scores for reference-sized blocks ---------------------------------
 
-def total_gcups_leg(algo, k, scores, q_host, s_rows_dev, ns, ns_pad, length, dev, n_blocks=10):
+def total_gcups_leg(algo, k, scores, q_host, s_rows_dev, ns, ns_pad, length, dev, n_blocks=1 << 30):
     """Raw subject rows in pinned host memory -> H2D -> GPU preprocess -> per block of REF_BUCKET_COUNT
     queries: kernel on one stream, D2H of the previous block's scores on another (two result buffers) ->
-    scores in pinned host memory.  Wall time of all of it = the reference's Total GCUPS
-    (cal_cpu.c:473-474) without the file I/O (the reference keeps that outside too: its I/O threads)."""
+    scores in pinned host memory (two buffers, overwritten as a writer thread would drain them).  The whole
+    query set by default.  Wall time of all of it = the reference's Total GCUPS (cal_cpu.c:473-474) without the
+    file I/O (the reference keeps that outside too: its I/O threads)."""
     L = B.lib()
     nq = min(q_host.shape[0], n_blocks * REF_BUCKET_COUNT)
     n_blocks = (nq + REF_BUCKET_COUNT - 1) // REF_BUCKET_COUNT

@@ -67,8 +67,8 @@ def main() -> int:
             if kind == "bitpal_factor":
                 f = int(rng.integers(2, 5))
                 scores = tuple(f * x for x in scores)
-                if rng.random() < 0.3:          # a mismatch below two gaps runs as its mismatch = 2*gap instance
-                    scores = (scores[0], min(scores[1], 2 * scores[2]) - int(rng.integers(0, 7)), scores[2])
+                if scores[1] == 2 * scores[2]:  # a mismatch below two gaps runs as its mismatch = 2*gap instance
+                    scores = (scores[0], scores[1] - int(rng.integers(0, 7)), scores[2])
                 if rng.random() < 0.15:         # edit-distance sets run on the Myers body
                     scores = (0, -f, -f)
             semi = kind == "bitpal_semi"
