@@ -14,7 +14,6 @@
 #include <map>
 #include <memory>
 #include <mutex>
-#include <set>
 #include <string>
 #include <thread>
 #include <utility>
@@ -253,8 +252,9 @@ void init_mapping_table(void)
 // out page-locked memory makes all of the host seams' copies full-rate DMA without the host code knowing.
 // Small blocks, and everything when no GPU is visible, come from the C heap.
 static std::mutex g_pinned_mu;
-static std::set<void *> g_pinned;
+static std::map<void *, size_t> g_pinned;
 static const size_t kPinThreshold = 1u << 20;
+static void forget_host_range(const void *p, size_t bytes);   // a freed buffer cannot stay a resident bucket
 
 void *malloc_mem(uint64_t size)
 {
@@ -264,7 +264,7 @@ void *malloc_mem(uint64_t size)
         if (hipGetDeviceCount(&n) == hipSuccess && n > 0 &&
             hipHostMalloc(&p, size, hipHostMallocPortable) == hipSuccess && p) {
             std::lock_guard<std::mutex> lock(g_pinned_mu);
-            g_pinned.insert(p);
+            g_pinned[p] = size;
             return p;
         }
         (void)hipGetLastError();
@@ -276,16 +276,20 @@ void *malloc_mem(uint64_t size)
 void free_mem(void *mem)
 {
     if (!mem) return;
+    size_t pinned_bytes = 0;
     {
         std::lock_guard<std::mutex> lock(g_pinned_mu);
         auto it = g_pinned.find(mem);
         if (it != g_pinned.end()) {
+            pinned_bytes = it->second;
             g_pinned.erase(it);
-            (void)hipHostFree(mem);
-            return;
         }
     }
-    free(mem);
+    forget_host_range(mem, pinned_bytes ? pinned_bytes : 1);
+    if (pinned_bytes)
+        (void)hipHostFree(mem);
+    else
+        free(mem);
 }
 
 int bgsa_hip_select_algorithm(int algo)
@@ -812,6 +816,12 @@ static void drop_overlapping(const unsigned char *lo, size_t bytes)  // g_seam h
             i++;
         }
     }
+}
+
+static void forget_host_range(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    if (!g_host.ranges.empty()) drop_overlapping(static_cast<const unsigned char *>(p), bytes);
 }
 
 static int seam_stream()  // g_seam held

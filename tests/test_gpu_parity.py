@@ -461,6 +461,23 @@ def test_host_seam_keeps_the_bucket_resident(oracle):
     L.hip_handle_reads(ctypes.byref(seq2), peq.ctypes.data, wn, 0, 256)
     L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, 150, 12, 150, 256, 0, 4, wn, 27, None)
     assert np.array_equal(out, oracle.myers64(q[:4], s2)) and uploads() == before + 2
+    # a bucket buffer handed back with free_mem() stops being resident: a new buffer at the same address, filled
+    # by other means, is uploaded afresh
+    nbytes = peq.nbytes
+    pa = L.malloc_mem(nbytes)
+    a = np.ctypeslib.as_array(ctypes.cast(pa, ctypes.POINTER(ctypes.c_uint32)), shape=(peq.size,))
+    a[:] = 0
+    L.hip_handle_reads(ctypes.byref(seq), pa, wn, 0, 256)          # subjects s
+    L.hip_cal_align_score(qmapped.ctypes.data, pa, out.ctypes.data, 150, 12, 150, 256, 0, 4, wn, 27, None)
+    assert np.array_equal(out, oracle.myers64(q[:4], s))
+    n1 = uploads()
+    L.free_mem(pa)
+    pb = L.malloc_mem(nbytes)
+    b = np.ctypeslib.as_array(ctypes.cast(pb, ctypes.POINTER(ctypes.c_uint32)), shape=(peq.size,))
+    b[:] = peq                                                       # subjects s2, written without hip_handle_reads
+    L.hip_cal_align_score(qmapped.ctypes.data, pb, out.ctypes.data, 150, 12, 150, 256, 0, 4, wn, 27, None)
+    assert np.array_equal(out, oracle.myers64(q[:4], s2)) and uploads() == n1 + 1
+    L.free_mem(pb)
     # stateless mode: every call uploads
     assert L.bgsa_hip_set_auto_resident(0) == 0
     try:
