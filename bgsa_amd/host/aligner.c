@@ -102,9 +102,10 @@ typedef struct {
     pthread_cond_t cond;
 } ring_t;
 
-/* One block goes to the file as n_writers slices written concurrently with pwrite(): a single fwrite() stream
- * (the reference's output thread, thread.c:150-160) moves ~6 GB/s into the page cache, the GPU produces scores
- * at ~19 GB/s (10k x 1M Myers), so the one thread was what bounded Total GCUPS. */
+/* A block goes to the file with pwrite() at its own offset, optionally as BGSA_WRITER_THREADS concurrent slices.
+ * Default 1: the result file is what bounds Total GCUPS (10k x 1M Myers: the GPU produces 19 GB/s of scores, one
+ * stream into a tmpfs page cache takes 6.4 GB/s), but more streams do not help there — 4 / 8 / 16 threads measured
+ * 5.0 / 5.9 / 3.4 s against 3.1 s with one (page-cache allocation serialises); a striped file system may differ. */
 typedef struct {
     int fd;
     const char *src;
@@ -468,7 +469,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < RING; i++) CK(bgsa_hip_malloc_host(&ring.host[i], block_bytes));
     ring.fd = open(file_result, O_CREAT | O_TRUNC | O_RDWR, 0644);
     if (ring.fd < 0) { printf("Error - can't open or create file: %s\n", file_result); exit(1); }
-    ring.n_writers = 8;
+    ring.n_writers = 1;
     if (getenv("BGSA_WRITER_THREADS")) ring.n_writers = atoi(getenv("BGSA_WRITER_THREADS"));
     if (ring.n_writers < 1) ring.n_writers = 1;
     if (ring.n_writers > 16) ring.n_writers = 16;
