@@ -287,12 +287,20 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("[bench] no GPU visible: the HIP path has no CPU fallback", file=sys.stderr)
         return 2
+    # Rehearsal of the N > 1 code on a one-GPU box (not a measurement): BGSA_BENCH_SAME_GPU=1 puts every rank on
+    # device 0 and BGSA_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
+    if os.environ.get("BGSA_BENCH_SAME_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("BGSA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run: RCCL even for one rank
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     algo, cfg_name, nq, ns_total, length, k, scaling = CONFIGS[args.config]
     scores = tuple(int(x) for x in args.scores.split(",")) if args.scores else None
@@ -319,7 +327,7 @@ def main() -> int:
         ns = ns_total                                # every rank its own full bucket
     q_rows, s_rows, ns_pad = make_workload(args.config, algo, nq, ns, length, k, mix, rank, dev, dist)
 
-    aligner = B.DeviceAligner(algo, f"cuda:{local_rank}", k, scores if algo == B.ALGO_BITPAL else None)
+    aligner = B.DeviceAligner(algo, str(dev), k, scores if algo == B.ALGO_BITPAL else None)
     q_host = q_rows.cpu().numpy()
     aligner.set_queries(q_host)
     aligner.set_subject_rows_device(s_rows.reshape(-1), ns_pad, length, qlen=length)
