@@ -150,3 +150,45 @@ print("NOT REACHED")
     assert p.returncode == 1, p.stdout + p.stderr
     assert "clean call ok" in p.stdout and "NOT REACHED" not in p.stdout
     assert "Error - hip_cal_align_score" in p.stdout and "stream fault" in p.stdout
+
+
+def test_concurrent_callers_with_library_scratch(oracle):
+    """Two host threads, two streams, different algorithms and scores, both letting the library own the scratch
+    (d_workspace = NULL): the scratch is per (device, stream) and the parameters travel with the call, so neither
+    sees the other's streams or settings (process-global scratch and settings raced)."""
+    import threading
+    import torch
+    L = B.lib()
+    q = oracle.gen_reads(91, 24, 150)
+    s = oracle.gen_reads(92, 640, 150)
+    s[:24] = oracle.mutate(q, np.arange(24) % 7, 93)
+    want = {B.ALGO_MYERS: oracle.myers64(q, s), B.ALGO_BITPAL: oracle.bitpal(q, s), B.ALGO_BANDED: oracle.banded64(q, s, 8)}
+    errors = []
+
+    def worker(algo):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                a = B.DeviceAligner(algo, k=8)
+                a.set_queries(q)
+                a.set_subjects(s)
+                p = a.params()
+                out = torch.empty((24, a.ns), dtype=a.out_dtype, device="cuda:0")
+                for _ in range(40):
+                    out.zero_()
+                    B.check(L.bgsa_hip_cal_align_score_ex(ctypes.byref(p), a.d_content.data_ptr(), a.d_peq.data_ptr(), out.data_ptr(),
+                                                          150, 150, a.ns, 0, 24, a.wn, None, 0, ctypes.c_void_p(stream.cuda_stream)))
+                    stream.synchronize()
+                    if not np.array_equal(out[:, :640].cpu().numpy(), want[algo]):
+                        errors.append(f"algo {algo}: wrong scores")
+                        return
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(algo,)) for algo in (B.ALGO_MYERS, B.ALGO_BITPAL, B.ALGO_BANDED)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert L.bgsa_hip_stream_faults(1) == 0
