@@ -161,6 +161,71 @@ __global__ __launch_bounds__(256) void banded_kernel(
 
 namespace { int banded_impl(); }
 
+// One listed pair of the regroup pass (see "regrouping of sparse survivors" below): entry = (query - q0) << 8 | lane of
+// the wave's group; scored from row 0 with the recurrence, tests and final walk of banded_kernel<T>, the query
+// character selected per lane.  g = the group's Mext block, out_tile = &out[q0][group * 64].
+template <typename T>
+__device__ __forceinline__ void banded_finish_pair(uint32_t entry, const uint32_t *__restrict__ g, const char *__restrict__ content,
+                                                   int first_query_row, int len, int word_num, int k,
+                                                   int8_t *__restrict__ out_tile, long long ld)
+{
+    constexpr int W = BandWord<T>::bits;
+    const int ql = static_cast<int>(entry >> 8);
+    const uint32_t sl = entry & 63u;
+    const uint32_t *gl = g + sl;
+    const unsigned char *qrow = reinterpret_cast<const unsigned char *>(content) + static_cast<size_t>(first_query_row + ql) * (len + 1);
+    const int h = k;
+    const T band_mask = (k + h + 1 >= W) ? ~T(0) : ((T(1) << (k + h + 1)) - 1);
+    const uint32_t max_err = static_cast<uint32_t>(k + h + 1);
+    const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
+    T vp = 0, vn = 0;
+    uint32_t acc = 0;
+    bool dead = false;
+    uint32_t x0[kChars], x1[kChars], x2[kChars];
+#pragma unroll
+    for (int c = 0; c < kChars; c++) {
+        x0[c] = 0u;
+        x1[c] = gl[(c * word_num + 0) * kLanes];
+        x2[c] = gl[(c * word_num + 1) * kLanes];
+    }
+    for (int r0 = 0; r0 < len; r0 += 32) {
+        const int wi = r0 >> 5;
+#pragma unroll
+        for (int c = 0; c < kChars; c++) {
+            x0[c] = x1[c];
+            x1[c] = x2[c];
+            x2[c] = (wi + 2 < word_num) ? gl[(c * word_num + wi + 2) * kLanes] : 0u;
+        }
+        const int rows = len - r0 < 32 ? len - r0 : 32;
+        for (int j = 0; j < rows; j++) {
+            const int r = r0 + j;
+            uint32_t c = qrow[r];
+            c = c > 4u ? 0u : c;
+            const uint32_t a = c == 0 ? x0[0] : c == 1 ? x0[1] : c == 2 ? x0[2] : c == 3 ? x0[3] : x0[4];
+            const uint32_t b = c == 0 ? x1[0] : c == 1 ? x1[1] : c == 2 ? x1[2] : c == 3 ? x1[3] : x1[4];
+            T win = BandWord<uint32_t>::funnel(b, a, j);
+            if constexpr (W == 64) {
+                const uint32_t d = c == 0 ? x2[0] : c == 1 ? x2[1] : c == 2 ? x2[2] : c == 3 ? x2[3] : x2[4];
+                win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
+            }
+            if (r == k) acc = 0;
+            band_row<T>(win & band_mask, vp, vn, acc);
+            if (r + 1 == last_check) dead = static_cast<uint32_t>(k) + acc > max_err;
+        }
+    }
+    int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+    if (!dead) {
+        uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
+        for (int i = 0; i <= h; i++) {
+            err += static_cast<uint32_t>((vp >> i) & 1);
+            err -= static_cast<uint32_t>((vn >> i) & 1);
+            best = err < best ? err : best;
+        }
+        result = static_cast<int8_t>(best);
+    }
+    out_tile[static_cast<size_t>(ql) * ld + sl] = result;
+}
+
 // ---- generated row loop (gen_rows_asm.py: gen_banded_function) -----------------------------------
 #include "banded_rows_gen.inc"
 
@@ -209,64 +274,10 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
         if (n_regroup > kLanes - static_cast<int>(push_max) || (q == q1 && n_regroup > 0)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < n_regroup) {
-                using T = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
-                const uint32_t entry = regroup[lane];
-                const int ql = static_cast<int>(entry >> 8);
-                const uint32_t sl = entry & 63u;
-                const uint32_t *gl = g + sl;
-                const unsigned char *qrow = reinterpret_cast<const unsigned char *>(content) +
-                                            static_cast<size_t>(ref_start + q0 + ql) * (len + 1);
-                const T band_mask = static_cast<T>(band);
-                const uint32_t max_err = static_cast<uint32_t>(k + h + 1);
-                const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
-                T vp = 0, vn = 0;
-                uint32_t acc = 0;
-                bool dead = false;
-                uint32_t x0[kChars], x1[kChars], x2[kChars];
-#pragma unroll
-                for (int c = 0; c < kChars; c++) {
-                    x0[c] = 0u;
-                    x1[c] = gl[(c * word_num + 0) * kLanes];
-                    x2[c] = gl[(c * word_num + 1) * kLanes];
-                }
-                for (int r0 = 0; r0 < len; r0 += 32) {
-                    const int wi = r0 >> 5;
-#pragma unroll
-                    for (int c = 0; c < kChars; c++) {
-                        x0[c] = x1[c];
-                        x1[c] = x2[c];
-                        x2[c] = (wi + 2 < word_num) ? gl[(c * word_num + wi + 2) * kLanes] : 0u;
-                    }
-                    const int rows = len - r0 < 32 ? len - r0 : 32;
-                    for (int j = 0; j < rows; j++) {
-                        const int r = r0 + j;
-                        uint32_t c = qrow[r];
-                        c = c > 4u ? 0u : c;
-                        const uint32_t a = c == 0 ? x0[0] : c == 1 ? x0[1] : c == 2 ? x0[2] : c == 3 ? x0[3] : x0[4];
-                        const uint32_t b = c == 0 ? x1[0] : c == 1 ? x1[1] : c == 2 ? x1[2] : c == 3 ? x1[3] : x1[4];
-                        T win = BandWord<uint32_t>::funnel(b, a, j);
-                        if constexpr (WIDE) {
-                            const uint32_t d = c == 0 ? x2[0] : c == 1 ? x2[1] : c == 2 ? x2[2] : c == 3 ? x2[3] : x2[4];
-                            win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
-                        }
-                        if (r == k) acc = 0;
-                        band_row<T>(win & band_mask, vp, vn, acc);
-                        if (r + 1 == last_check) dead = static_cast<uint32_t>(k) + acc > max_err;
-                    }
-                }
-                int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
-                if (!dead) {
-                    uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
-                    for (int i = 0; i <= h; i++) {
-                        err += static_cast<uint32_t>((vp >> i) & 1);
-                        err -= static_cast<uint32_t>((vn >> i) & 1);
-                        best = err < best ? err : best;
-                    }
-                    result = static_cast<int8_t>(best);
-                }
-                out[static_cast<size_t>(q0 + ql) * ld + static_cast<size_t>(group) * kLanes + sl] = result;
-            }
+            if (lane < n_regroup)
+                banded_finish_pair<typename std::conditional<WIDE, uint64_t, uint32_t>::type>(
+                    regroup[lane], g, content, ref_start + q0, len, word_num, k,
+                    out + static_cast<size_t>(q0) * ld + static_cast<size_t>(group) * kLanes, ld);
             __builtin_amdgcn_wave_barrier();
             n_regroup = 0;
         }
@@ -336,6 +347,112 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
 // on a list (LDS, per wave); when the list is nearly full or the wave's query tile is done, the listed pairs
 // are scored one per lane, densely, from row 0 (banded_asm_kernel, top of the query loop).  Whatever gets
 // onto the list is scored exactly, so where the first pass stops is a pure performance choice.
+// ---- straight-line rows (k <= 15): banded_chunk_rows_asm32 ---------------------------------------------
+// Same task decomposition, tests, regrouping and final walk as banded_asm_kernel; what differs is how a row gets
+// its match words: the wave keeps them in LDS ([class][slot][lane] dwords, 3840 B per wave) and a row's token is the
+// byte offset of its class, so the 32 rows of a chunk are straight-line code with immediate shift amounts and no
+// scalar work per row (gen_rows_asm.py: gen_banded_chunk_function).  Tokens: one dword per row, 32 per chunk, packed
+// per launch by pack_banded_tokens_kernel.
+__global__ __launch_bounds__(256) void banded_chunk_kernel(
+    const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
+    long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int token_stride_bytes,
+    const char *__restrict__ content, int ref_start, int len, uint32_t push_row, uint32_t push_max)
+{
+    constexpr int NM = 3;
+    __shared__ uint32_t s_words[kWavesPerBlock][kChars][NM][kLanes];
+    __shared__ uint32_t s_regroup[kWavesPerBlock][kLanes];
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int wave = threadIdx.x >> 6;
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave);
+    if (group >= n_groups) return;
+    uint32_t *regroup = s_regroup[wave];
+    int n_regroup = 0;
+    const uint32_t *g = mext + static_cast<size_t>(group) * kChars * word_num * kLanes;
+    const unsigned long long gbase = uniform_u64(reinterpret_cast<unsigned long long>(g));
+    // LDS byte address of this lane's dword in the wave's block (LDS addresses are 32-bit offsets)
+    const uint32_t lanebase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&s_words[wave][0][0][lane]));
+
+    uint32_t first[kChars][NM];
+#pragma unroll
+    for (int c = 0; c < kChars; c++)
+#pragma unroll
+        for (int w = 0; w < NM; w++) first[c][w] = g[(c * word_num + w) * kLanes + lane];
+    const int h = k;
+    const uint32_t band = static_cast<uint32_t>((1ull << (k + h + 1)) - 1ull);
+    const uint32_t limit = static_cast<uint32_t>(h + 1);
+    const uint32_t last_check = static_cast<uint32_t>((len <= 64) ? len : ((len - h > 64) ? len - h : 64));
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int8_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q <= q1; q++) {
+        if (n_regroup > kLanes - static_cast<int>(push_max) || (q == q1 && n_regroup > 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n_regroup)
+                banded_finish_pair<uint32_t>(regroup[lane], g, content, ref_start + q0, len, word_num, k,
+                                             out + static_cast<size_t>(q0) * ld + static_cast<size_t>(group) * kLanes, ld);
+            __builtin_amdgcn_wave_barrier();
+            n_regroup = 0;
+        }
+        if (q == q1) break;
+        uint32_t st[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < kChars; c++)
+#pragma unroll
+            for (int w = 0; w < NM; w++) s_words[wave][c][w][lane] = first[c][w];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t voff[kChars];
+#pragma unroll
+        for (int c = 0; c < kChars; c++) voff[c] = static_cast<uint32_t>(((c * word_num + NM) * kLanes + lane) * 4);
+        int early;
+        const unsigned long long dead_mask = banded_chunk_rows_asm32(
+            st, voff, lanebase, uniform_u64(reinterpret_cast<unsigned long long>(tokens)),
+            __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(q) * static_cast<uint32_t>(token_stride_bytes)), gbase, band, limit,
+            static_cast<uint32_t>(k), last_check, static_cast<uint32_t>(len), push_row, push_max, early);
+        __builtin_amdgcn_wave_barrier();
+        const bool dead = (dead_mask >> lane) & 1ull;
+        if (early) {
+            const unsigned long long alive = ~dead_mask;
+            if (dead)
+                dst[static_cast<size_t>(q) * ld] = static_cast<int8_t>(HIP_MAX_ERROR);
+            else
+                regroup[n_regroup + __popcll(alive & ((1ull << lane) - 1ull))] = (static_cast<uint32_t>(q - q0) << 8) | lane;
+            n_regroup += __builtin_amdgcn_readfirstlane(static_cast<int>(__popcll(alive)));
+            continue;
+        }
+        int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+        if (dead_mask != ~0ull) {
+            uint32_t err = static_cast<uint32_t>(k) + st[2], best = err;
+            for (int i = 0; i <= h; i++) {
+                err += (st[0] >> i) & 1u;
+                err -= (st[1] >> i) & 1u;
+                best = err < best ? err : best;
+            }
+            if (!dead) result = static_cast<int8_t>(best);
+        }
+        dst[static_cast<size_t>(q) * ld] = result;
+    }
+}
+
+// Row tokens of banded_chunk_kernel: token[q][r] = class * 768 (the class's byte offset in the wave's LDS block),
+// zero beyond the query's end up to whole chunks of 32 rows.
+__global__ __launch_bounds__(256) void pack_banded_tokens_kernel(const char *__restrict__ content, uint32_t *__restrict__ tokens,
+                                                                 int len, int ref_start, int n_queries, int rows_padded)
+{
+    const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= static_cast<long long>(n_queries) * rows_padded) return;
+    const int q = static_cast<int>(tid / rows_padded), r = static_cast<int>(tid % rows_padded);
+    uint32_t c = 0;
+    if (r < len) {
+        c = static_cast<unsigned char>(content[static_cast<size_t>(ref_start + q) * (len + 1) + r]);
+        if (c > 4u) c = 0u;   // as the stream packers: out-of-alphabet bytes behave as 'A'
+    }
+    tokens[tid] = c * 768u;
+}
+
 namespace {
 
 // Regrouping policy (measurement knobs; any value gives the same scores): a wave puts its survivors on the
@@ -360,13 +477,42 @@ int banded_push_row_offset()
     return v;
 }
 
+// 0 = generated asm (default: straight-line chunk rows for k <= 15, threaded row loop for k >= 16),
+// 1 = compiler-scheduled C++ kernel (BGSA_BANDED_IMPL=c), 2 = threaded asm row loop for every k (BGSA_BANDED_IMPL=t:
+// the A/B reference of the chunk kernel).
 int banded_impl()
 {
     static const int impl = [] {
         const char *e = getenv("BGSA_BANDED_IMPL");
-        return (e && e[0] == 'c') ? 1 : 0;
+        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 't') ? 2 : 0);
     }();
     return impl;
+}
+
+int launch_chunk(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len, int64_t read_count,
+                 int ref_start, int ref_end, int word_num, int k, void *d_workspace, hipStream_t stream)
+{
+    const int nq = ref_end - ref_start;
+    const int64_t n_groups = read_count / kLanes;
+    int q_tile = 32;
+    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+              static_cast<unsigned>((nq + q_tile - 1) / q_tile));
+    if (grid.y > 65535u) {
+        set_error_text("banded: too many query tiles for one launch");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+    const int rows_padded = (len + 31) / 32 * 32;
+    const long long total = static_cast<long long>(nq) * rows_padded;
+    hipLaunchKernelGGL(pack_banded_tokens_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream,
+                       d_content, static_cast<uint32_t *>(d_workspace), len, ref_start, nq, rows_padded);
+    BGSA_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(banded_chunk_kernel, grid, dim3(256), 0, stream, static_cast<const uint32_t *>(d_workspace), d_peq,
+                       d_results, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k,
+                       rows_padded * 4, d_content, ref_start, len, static_cast<uint32_t>(k + banded_push_row_offset()),
+                       static_cast<uint32_t>(banded_push_max()));
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
 }
 
 int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len, int64_t read_count,
@@ -431,7 +577,8 @@ static thread_local int g_last_k = 8;  // threshold of this thread's last banded
 const char *banded_kernel_name(int word_num)
 {
     (void)word_num;
-    if (banded_impl() != 0) return g_last_k <= 15 ? "banded_kernel<uint32_t>" : "banded_kernel<uint64_t>";
+    if (banded_impl() == 1) return g_last_k <= 15 ? "banded_kernel<uint32_t>" : "banded_kernel<uint64_t>";
+    if (banded_impl() == 0 && g_last_k <= 15) return "banded_chunk_kernel";
     return g_last_k <= 15 ? "banded_asm_kernel<false>" : "banded_asm_kernel<true>";
 }
 
@@ -449,7 +596,10 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
         return BGSA_HIP_EUNSUPPORTED;
     }
     g_last_k = k;
-    if (banded_impl() == 0)
+    if (banded_impl() == 0 && k <= 15)
+        return launch_chunk(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
+                            d_workspace, stream);
+    if (banded_impl() != 1)
         return launch_asm(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                           d_workspace, stream);
     if (k <= 15)

@@ -116,7 +116,9 @@ constexpr int kBandedCheckRows = 8;
 inline size_t banded_stream_bound(int len)
 {
     const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 + 4;
-    return (static_cast<size_t>(len) + 3 * events + 1 + 6) / 7 * 8 + 16;
+    const size_t threaded = (static_cast<size_t>(len) + 3 * events + 1 + 6) / 7 * 8 + 16;
+    const size_t chunk_tokens = (static_cast<size_t>(len) + 31) / 32 * 32 * 4;   // banded_chunk_kernel: one dword per row
+    return threaded > chunk_tokens ? threaded : chunk_tokens;
 }
 __host__ __device__ inline int banded_stream_layout(int len, int k, const char *row, unsigned char *dst)
 {

@@ -462,6 +462,219 @@ __device__ __forceinline__ unsigned long long banded_rows_asm{64 if wide else 32
 """
 
 
+def gen_banded_chunk_function() -> str:
+    """Banded row loop for the 32-bit band (k <= 15) WITHOUT a per-row jump: straight-line code for 32 rows, the
+    query character selecting the match words through an LDS ADDRESS instead of a branch.
+
+    The threaded loop (gen_banded_function) pays 6 scalar instructions of dispatch per token plus a shift counter per
+    row, events and refills — 7.85 SALU per wave-row against 13 VALU, and a CU has ONE scalar unit for its four SIMDs:
+    4 x 7.85 scalar issue slots per ~31-cycle row saturate it (adding four dummy SALU per row cost 43 %).
+    Here the wave keeps its match words in LDS ([class][slot lo/hi/next][lane]); a row's token is the byte offset of its
+    class (one SGPR per row, 32 loaded at a time with two s_load_dwordx16), the row reads its two words with
+    ds_read_b32 at `lane base + token` two rows ahead, and the funnel shift amount is the row's position in the chunk —
+    an immediate.  Per row: 13 VALU, 2 LDS reads, and no scalar instruction at all in the chunks that hold no special
+    row; a chunk that holds row k (error count starts), the last checkpoint (reject mask latched) or the query's end
+    runs a second copy of the 32 rows with a two-instruction check behind every row.  Tests every 8 rows are inline,
+    enabled by a per-chunk mask; every 32 rows the words move down one slot and the next one, fetched from global
+    memory during the chunk, takes the free slot."""
+    body = R.banded_body()
+    slot_of, n_slots = body.allocate_temps()
+    TOK0 = 60                       # s[60:91]: the 32 row tokens of the current chunk
+    S_RET, S_RET_LO, S_RET_HI = "s[92:93]", "s92", "s93"
+    clobbers = [f"s{i}" for i in range(60, 94)] + ["vcc", "scc", "memory"]
+    NM = 3
+
+    def reg_row(j: int):
+        pipe = j % 3
+        def reg(name: str) -> str:
+            if name.startswith("S"):
+                return f"%[s{name[1:]}]"
+            if name == "E0":
+                return f"%[lo{pipe}]"
+            if name == "E1":
+                return f"%[hi{pipe}]"
+            if name in ("$mask", "$mask_lo"):
+                return "%[mask]"
+            if name == "$sh":
+                return str(j)
+            if name == "$one":
+                return "1"
+            return f"%[t{slot_of[name]}]"
+        return reg
+
+    def fetch(j: int) -> list[str]:
+        pipe = j % 3
+        return [f"v_add_u32 %[vaddr], s{TOK0 + j}, %[lanebase]",
+                f"ds_read_b32 %[lo{pipe}], %[vaddr]",
+                f"ds_read_b32 %[hi{pipe}], %[vaddr] offset:256"]
+
+    def rows(tag: str, checked: bool) -> list[str]:
+        out = fetch(0) + fetch(1)
+        for j in range(32):
+            if j + 2 < 32:
+                out += fetch(j + 2)
+            out.append(f"s_waitcnt lgkmcnt({2 * min(2, 31 - j)})")
+            out += body.emit_asm(reg_row(j), 0)
+            if j % 8 == 7:   # a test after every 8th row, if this chunk's mask enables it
+                idx = j // 8
+                out += [
+                    f"s_bitcmp1_b32 %[testen], {idx}",
+                    f"s_cbranch_scc0 L_{tag}_nt{idx}_%=",
+                    "v_cmp_lt_u32 vcc, %[thr], %[s2]",
+                    "s_andn2_b64 %[alive], exec, vcc",
+                    "s_cbranch_scc0 L_alldead_%=",
+                    # few survivors late enough: hand them to the regroup list (banded.hip)
+                    f"s_add_u32 %[cnt], %[row0], {j + 1}",
+                    "s_cmp_ge_u32 %[cnt], %[pushrow]",
+                    f"s_cbranch_scc0 L_{tag}_nt{idx}_%=",
+                    "s_bcnt1_i32_b64 %[cnt], %[alive]",
+                    "s_cmp_le_u32 %[cnt], %[pushmax]",
+                    f"s_cbranch_scc0 L_{tag}_nt{idx}_%=",
+                    "s_mov_b64 %[dead], vcc",
+                    "s_mov_b32 %[early], 1",
+                    "s_branch L_done_%=",
+                    f"L_{tag}_nt{idx}_%=:",
+                ]
+            if checked:
+                out += [f"s_bitcmp1_b32 %[ev], {j}", f"s_cbranch_scc1 L_sp{j}_%=", f"L_ret{j}_%=:"]
+        return out
+
+    asm = [
+        "s_mov_b32 %[early], 0",
+        "s_mov_b64 %[dead], 0",
+        "s_mov_b32 %[row0], 0",
+        "L_chunk_%=:",
+        # this chunk's tokens; the next match word of every class, due when the chunk ends
+        f"s_load_dwordx16 s[{TOK0}:{TOK0 + 15}], %[tokbase], %[tokoff]",
+        "s_add_u32 %[cnt], %[tokoff], 64",
+        f"s_load_dwordx16 s[{TOK0 + 16}:{TOK0 + 31}], %[tokbase], %[cnt]",
+        "s_add_u32 %[tokoff], %[tokoff], 128",
+    ]
+    asm += [f"global_load_dword %[next{c}], %[voff{c}], %[gbase]" for c in range(5)]
+    asm += [f"v_add_u32 %[voff{c}], 0x100, %[voff{c}]" for c in range(5)]
+    # special rows of this chunk: bit j of `ev` = something happens once row j is done (rows done = row0 + j + 1)
+    asm += ["s_mov_b32 %[ev], 0"]
+    for what in ("k", "last", "len"):
+        asm += [
+            f"s_sub_u32 %[cnt], %[{what}], %[row0]",
+            "s_sub_u32 %[cnt], %[cnt], 1",
+            "s_cmp_lt_u32 %[cnt], 32",                 # unsigned: also false when the row lies before this chunk
+            f"s_cbranch_scc0 L_no_{what}_%=",
+            "s_lshl_b32 %[cnt], 1, %[cnt]",
+            "s_or_b32 %[ev], %[ev], %[cnt]",
+            f"L_no_{what}_%=:",
+        ]
+    # tests after rows 8, 16, 24, 32 of the chunk: enabled while k < rows done <= last
+    asm += ["s_mov_b32 %[testen], 0"]
+    for idx in range(4):
+        asm += [
+            f"s_add_u32 %[cnt], %[row0], {8 * (idx + 1)}",
+            "s_cmp_gt_u32 %[cnt], %[k]",
+            f"s_cbranch_scc0 L_te{idx}_%=",
+            "s_cmp_le_u32 %[cnt], %[last]",
+            f"s_cbranch_scc0 L_te{idx}_%=",
+            f"s_bitset1_b32 %[testen], {idx}",
+            f"L_te{idx}_%=:",
+        ]
+    asm += [
+        "s_waitcnt lgkmcnt(0)",
+        "s_cmp_eq_u32 %[ev], 0",
+        "s_cbranch_scc0 L_checked_%=",
+    ]
+    asm += rows("f", False)
+    asm.append("s_branch L_advance_%=")
+    asm.append("L_checked_%=:")
+    asm += rows("c", True)
+    asm.append("L_advance_%=:")
+    asm.append("s_add_u32 %[row0], %[row0], 32")
+    # the words move down one slot; the one fetched during the chunk takes the free slot
+    for c in range(5):
+        base = c * NM * 256
+        asm += [f"ds_read_b32 %[lo0], %[lanebase] offset:{base + 256}",
+                f"ds_read_b32 %[hi0], %[lanebase] offset:{base + 512}",
+                "s_waitcnt lgkmcnt(0)",
+                f"ds_write_b32 %[lanebase], %[lo0] offset:{base}",
+                f"ds_write_b32 %[lanebase], %[hi0] offset:{base + 256}"]
+    asm.append("s_waitcnt vmcnt(0)")
+    for c in range(5):
+        asm.append(f"ds_write_b32 %[lanebase], %[next{c}] offset:{c * NM * 256 + 512}")
+    asm += ["s_waitcnt lgkmcnt(0)", "s_branch L_chunk_%="]
+    # ---- out of line: what a special row does, then back behind that row
+    for j in range(32):
+        asm += [f"L_sp{j}_%=:", f"s_mov_b32 %[jreg], {j}", "s_branch L_special_%="]
+    asm += [
+        "L_special_%=:",
+        "s_add_u32 %[cnt], %[row0], %[jreg]",
+        "s_add_u32 %[cnt], %[cnt], 1",                  # rows done
+        "s_cmp_eq_u32 %[cnt], %[last]",                 # the reference's last checkpoint: latch the reject mask
+        "s_cbranch_scc0 L_sp_nolatch_%=",
+        "v_cmp_lt_u32 vcc, %[thr], %[s2]",
+        "s_mov_b64 %[dead], vcc",
+        "L_sp_nolatch_%=:",
+        "s_cmp_eq_u32 %[cnt], %[k]",                    # scoring starts at row k
+        "s_cbranch_scc0 L_sp_noreset_%=",
+        "v_mov_b32 %[s2], 0",
+        "L_sp_noreset_%=:",
+        "s_cmp_eq_u32 %[cnt], %[len]",
+        "s_cbranch_scc1 L_done_%=",
+        f"s_getpc_b64 {S_RET}",
+        "L_tabanchor_%=:",
+        "s_lshl_b32 %[cnt], %[jreg], 2",
+        f"s_add_u32 {S_RET_LO}, {S_RET_LO}, %[cnt]",
+        f"s_addc_u32 {S_RET_HI}, {S_RET_HI}, 0",
+        f"s_add_u32 {S_RET_LO}, {S_RET_LO}, (L_rettab_%= - L_tabanchor_%=)",
+        f"s_addc_u32 {S_RET_HI}, {S_RET_HI}, 0",
+        f"s_setpc_b64 {S_RET}",
+        "L_rettab_%=:",
+    ]
+    asm += [f"s_branch L_ret{j}_%=" for j in range(32)]
+    asm += [
+        "L_alldead_%=:",
+        "s_mov_b64 %[dead], exec",
+        "L_done_%=:",
+        "s_waitcnt vmcnt(0) lgkmcnt(0)",
+    ]
+
+    text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(3)]
+    outs += [f'[voff{c}] "+v"(voff[{c}])' for c in range(5)]
+    outs += ['[tokoff] "+s"(tokoff)', '[dead] "=&s"(dead)', '[early] "=&s"(early)', '[row0] "=&s"(row0)', '[ev] "=&s"(ev)',
+             '[testen] "=&s"(testen)', '[cnt] "=&s"(cnt)', '[jreg] "=&s"(jreg)', '[alive] "=&s"(alive)']
+    outs += [f'[lo{i}] "=&v"(lo[{i}])' for i in range(3)] + [f'[hi{i}] "=&v"(hi[{i}])' for i in range(3)]
+    outs += [f'[next{c}] "=&v"(nxt[{c}])' for c in range(5)]
+    outs += ['[vaddr] "=&v"(vaddr)']
+    outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
+    ins = ['[lanebase] "v"(lanebase)', '[tokbase] "s"(tokens)', '[gbase] "s"(gbase)', '[mask] "s"(band_mask)', '[thr] "s"(limit)',
+           '[k] "s"(k)', '[last] "s"(last)', '[len] "s"(len)', '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
+    clob = ", ".join(f'"{x}"' for x in clobbers)
+    return f"""
+// Straight-line banded rows, 32-bit band (gen_rows_asm.py: gen_banded_chunk_function): {body.valu_count()} + 1 VALU and two LDS reads per
+// row, no scalar instruction per row outside the chunks that hold row k, the last checkpoint or the query's end.
+// state = {{VP, VN, errors since row k}}; lanebase = LDS byte address of this lane's dword in the wave's match-word block
+// ([class][slot][lane], slots = words of the current chunk: lo, hi, next); tokens + tokoff = this query's row tokens
+// (one dword per row = class * 768, 32 per chunk, zero-padded to whole chunks); voff[c] = byte offset of class c's next
+// word to fetch relative to gbase (the group's Mext block).  Returns the reject mask; early as banded_rows_asm32.
+__device__ __forceinline__ unsigned long long banded_chunk_rows_asm32(uint32_t (&state)[3], uint32_t (&voff)[5], const uint32_t lanebase,
+                                                                   const unsigned long long tokens, uint32_t tokoff,
+                                                                   const unsigned long long gbase, const uint32_t band_mask,
+                                                                   const uint32_t limit, const uint32_t k, const uint32_t last,
+                                                                   const uint32_t len, const uint32_t push_row, const uint32_t push_max,
+                                                                   int &early_out)
+{{
+    uint32_t tmp[{max(n_slots, 1)}], lo[3], hi[3], nxt[5], vaddr, row0, ev, testen, cnt, jreg;
+    int early;
+    unsigned long long dead, alive;
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+    early_out = early;
+    return dead;
+}}
+"""
+
+
 def gen_blocked_function(fn_name: str, nw: int, body: R.Body, n_base: int, n_chains: int, n_planes: int, n_eq: int) -> str:
     """Row loop of a column-block kernel: one block of a long subject.  Stream code 7 (no
     argument) every 32 rows = CARRY: store the carry-out words of the finished 32 rows to the
@@ -692,7 +905,8 @@ def main() -> int:
     # ---- BitPAl, default scores (other score sets: gen_bitpal_sets.py) ------------------------
     (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))
     # ---- banded -------------------------------------------------------------------------------
-    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(True))
+    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(True) +
+                                              gen_banded_chunk_function())
     return 0
 
 

@@ -34,6 +34,8 @@ def clobbered(func: str) -> set:
         regs |= {80, 81}
     if "banded_asm_kernel" in func:
         regs |= set(range(72, 96))
+    if "banded_chunk_kernel" in func:
+        regs = set(range(60, 94))
     return regs
 
 
@@ -81,7 +83,7 @@ def check(asm_text: str, name: str):
                         # hand-over moves between the compiler's operands and the loop's hard-coded registers
                         # hand-over moves: before L_anchor the sources are the compiler's operands, after L_done the
                         # destinations are; neither may sit in a register the loop hard-codes
-                        if code.startswith("L_anchor"):
+                        if code.startswith("L_anchor") or code.startswith("L_chunk"):
                             phase = "loop"
                         elif code.startswith("L_done"):
                             phase = "epilogue"
@@ -94,7 +96,8 @@ def check(asm_text: str, name: str):
                         continue
                     if code.startswith("s_bfe_i64"):
                         problems.append(f"{name}: {func}: s_bfe_i64 (sign-extended 64-bit scalar) feeds an asm kernel: {code}")
-                if "global_atomic_or" not in body:
+                # (the chunk kernel has no token dispatch: a damaged token can only select a wrong LDS word, never a jump)
+                if "global_atomic_or" not in body and "banded_chunk_kernel" not in func:
                     problems.append(f"{name}: {func}: no global_atomic_or — the stream-fault report is missing")
             func = None
     return kernels, problems
