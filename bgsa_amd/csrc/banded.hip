@@ -477,14 +477,18 @@ int banded_push_row_offset()
     return v;
 }
 
-// 0 = generated asm (default: straight-line chunk rows for k <= 15, threaded row loop for k >= 16),
-// 1 = compiler-scheduled C++ kernel (BGSA_BANDED_IMPL=c), 2 = threaded asm row loop for every k (BGSA_BANDED_IMPL=t:
-// the A/B reference of the chunk kernel).
+// 0 = generated asm, threaded row loop (default), 1 = compiler-scheduled C++ kernel (BGSA_BANDED_IMPL=c),
+// 2 = generated asm, straight-line chunk rows for k <= 15 (BGSA_BANDED_IMPL=s).  The straight-line kernel removes the
+// scalar work per row (7.85 SALU per wave-row in the threaded loop, on a scalar unit shared by the CU's four SIMDs) at
+// the price of one more VALU, two LDS reads per row and a slot rotation every 32 rows; measured on 10k x 1M x 150 bp,
+// k = 8, same box, threaded / straight-line: random pairs 111.6 / 117.7 ms, 1 % dense survivors 171.8 / 163.7,
+// every pair surviving 384.2 / 393.5 — no better where it matters, so the threaded loop stays the default and this
+// one the measured alternative.
 int banded_impl()
 {
     static const int impl = [] {
         const char *e = getenv("BGSA_BANDED_IMPL");
-        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 't') ? 2 : 0);
+        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 's') ? 2 : 0);
     }();
     return impl;
 }
@@ -578,7 +582,7 @@ const char *banded_kernel_name(int word_num)
 {
     (void)word_num;
     if (banded_impl() == 1) return g_last_k <= 15 ? "banded_kernel<uint32_t>" : "banded_kernel<uint64_t>";
-    if (banded_impl() == 0 && g_last_k <= 15) return "banded_chunk_kernel";
+    if (banded_impl() == 2 && g_last_k <= 15) return "banded_chunk_kernel";
     return g_last_k <= 15 ? "banded_asm_kernel<false>" : "banded_asm_kernel<true>";
 }
 
@@ -596,7 +600,7 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
         return BGSA_HIP_EUNSUPPORTED;
     }
     g_last_k = k;
-    if (banded_impl() == 0 && k <= 15)
+    if (banded_impl() == 2 && k <= 15)
         return launch_chunk(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                             d_workspace, stream);
     if (banded_impl() != 1)
