@@ -747,7 +747,7 @@ def test_config0_hip_matches_live_reference(oracle):
 @pytest.mark.parametrize("algo,k,nq,ns,length", [(B.ALGO_MYERS, 0, 10_000, 1_000_000, 150),
                                                  (B.ALGO_BANDED, 8, 10_000, 1_000_000, 150),
                                                  (B.ALGO_BITPAL, 0, 10_000, 1_000_000, 150),
-                                                 (B.ALGO_MYERS, 0, 1_000, 125_000, 1000)])   # configs[4], one GPU's shard
+                                                 (B.ALGO_MYERS, 0, 1_000, 1_000_000, 1000)])   # configs[4]: the whole bucket on one GPU
 def test_full_baseline_size_properties(oracle, algo, k, nq, ns, length):
     import torch
     dev = torch.device("cuda:0")
