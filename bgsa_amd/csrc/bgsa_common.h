@@ -113,6 +113,7 @@ constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill 
 // reference tests every 16 rows (banded/BGSA_CPU/config.h: batch_size); the errors never decrease, so
 // testing more often rejects exactly the same pairs, only sooner.
 constexpr int kBandedCheckRows = 8;
+constexpr int kBandedLateRows = 48;   // from row k + 48 on the tests come every 16 rows
 inline size_t banded_stream_bound(int len)
 {
     const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 + 4;
@@ -149,8 +150,16 @@ __host__ __device__ inline int banded_stream_layout(int len, int k, const char *
     };
     // events due before row r starts / after `done` rows are complete
     auto before = [&](int r) { return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0); };
+    // Tests between checkpoints only decide how soon a wave may stop, never the result (the errors are monotone and
+    // the reject mask is latched at `last`): none before a lane can be past the limit at all (more than k + 1 errors
+    // need more than k + 1 scored rows), every kBandedCheckRows rows while random pairs are dying, every
+    // 2 * kBandedCheckRows once they are dead (k + kBandedLateRows rows on) — what is still alive then mostly stays.
     auto after = [&](int done) {
-        return (done > k && done <= last && ((done & (kBandedCheckRows - 1)) == 0 || done == last)) ? (4 | (done == last ? 8 : 0)) : 0;
+        if (!(done > k && done <= last)) return 0;
+        if (done == last) return 4 | 8;
+        if ((done & (kBandedCheckRows - 1)) != 0 || done - k <= k + 1) return 0;
+        if (done > k + kBandedLateRows && (done & (2 * kBandedCheckRows - 1)) != 0) return 0;
+        return 4;
     };
     for (int r = 0; r < len;) {
         pending |= before(r);

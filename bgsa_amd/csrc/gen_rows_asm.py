@@ -377,6 +377,26 @@ def gen_banded_function(wide: bool) -> str:
     asm += [
         f"s_and_b32 {S_ARG}, {S_WIN_LO}, 0xff",
         f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
+        # by far the most frequent event is the plain test (argument 4): its own short path, no bit tests
+        f"s_cmp_eq_u32 {S_ARG}, 4",
+        "s_cbranch_scc0 L_ev_general_%=",
+        f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc}]",
+        f"s_andn2_b64 {S_TMP}, exec, vcc",
+        "s_cbranch_scc0 L_ev_alldead_%=",
+        f"s_lshl_b32 {S_CNT}, {S_CHUNK}, 5",
+        f"s_add_u32 {S_CNT}, {S_CNT}, {S_SH}",
+        f"s_cmp_ge_u32 {S_CNT}, {S_PUSHROW}",
+        "s_cbranch_scc0 L_ev_out_%=",
+        f"s_bcnt1_i32_b64 {S_CNT}, {S_TMP}",
+        f"s_cmp_le_u32 {S_CNT}, {S_PUSHMAX}",
+        "s_cbranch_scc0 L_ev_out_%=",
+        f"s_mov_b64 {S_DEAD}, vcc",
+        f"s_mov_b32 {S_EARLY}, 1",
+        "s_branch L_done_%=",
+        "L_ev_alldead_%=:",
+        f"s_mov_b64 {S_DEAD}, exec",
+        "s_branch L_done_%=",
+        "L_ev_general_%=:",
         # bit 2: test err > limit on every lane; bit 3: latch the reject mask (last checkpoint)
         f"s_bitcmp1_b32 {S_ARG}, 2",
         "s_cbranch_scc0 L_ev_reset_%=",

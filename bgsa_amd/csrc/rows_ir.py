@@ -654,6 +654,7 @@ def banded_last_check(length: int, k: int) -> int:
 
 
 BANDED_CHECK_ROWS = 8   # bgsa_common.h: kBandedCheckRows
+BANDED_LATE_ROWS = 48   # bgsa_common.h: kBandedLateRows
 
 
 def banded_tokens(length: int, k: int, word_bits: int = 32):
@@ -673,8 +674,12 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
             pending = 0
         out.append(("row", r))
         done = r + 1
-        if done > k and done <= last and (done % BANDED_CHECK_ROWS == 0 or done == last):
-            pending |= 4 | (8 if done == last else 0)
+        if done > k and done <= last:
+            if done == last:
+                pending |= 4 | 8
+            elif done % BANDED_CHECK_ROWS == 0 and done - k > k + 1 and \
+                    not (done > k + BANDED_LATE_ROWS and done % (2 * BANDED_CHECK_ROWS) != 0):
+                pending |= 4
     if pending:
         out.append(("event", pending))
     return out
