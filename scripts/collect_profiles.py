@@ -22,12 +22,12 @@ HELPERS = ("pack", "preprocess", "map_queries", "scale_scores", "corrupt_stream"
 for c in (2, 3, 4, 5):
     b = src / f"bench_cfg{c}.json"
     if b.exists() and b.stat().st_size:
-        line = b.read_text().strip().splitlines()[-1]
+        line = [x for x in b.read_text().strip().splitlines() if x.startswith("{")][-1]
         json.loads(line)   # must be the one JSON line of the contract
         (dst / f"{prefix}_cfg{c}_bench.json").write_text(line + "\n")
-    stats = glob.glob(str(src / f"prof_cfg{c}" / "**" / "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(str(src / f"prof_cfg{c}" / "**" / "*kernel_stats.csv"), recursive=True), key=lambda f: Path(f).stat().st_mtime)
     if stats:
-        shutil.copy(stats[0], dst / f"{prefix}_cfg{c}_kernel_stats.csv")
+        shutil.copy(stats[-1], dst / f"{prefix}_cfg{c}_kernel_stats.csv")
 
 # PMC: value per launch of the scoring kernel, one file per config (and banded mix)
 groups = {}
@@ -38,11 +38,11 @@ for d in sorted(glob.glob(str(src / "pmc_cfg*"))):
 for key, dirs in groups.items():
     rows = []
     for d in dirs:
-        files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+        files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=lambda f: Path(f).stat().st_mtime)
         if not files:
             continue
         per = {}
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(files[-1])):      # the latest run into this directory
             name = r["Kernel_Name"]
             if "bgsa::" not in name or any(h in name for h in HELPERS):
                 continue
