@@ -63,3 +63,42 @@ def test_two_ranks_hip_compute_and_streamed_gather(tmp_path, oracle, algo, layou
         else:
             parts += [blk[:, sh.start: sh.start + sh.count].reshape(-1) for sh in shards]
     assert np.array_equal(got, np.concatenate(parts))
+
+
+def _bench_two_ranks(extra_env, extra_args=()):
+    """bench.py exactly as the driver starts it for N = 2, except that both ranks share this box's one card and the
+    collectives go through gloo (BGSA_BENCH_SAME_GPU / BGSA_BENCH_BACKEND: a rehearsal of the code path, not a
+    measurement)."""
+    import json
+    import subprocess
+    env = dict(os.environ, BGSA_BENCH_SAME_GPU="1", BGSA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--nq", "300", "--ns", "64000", *extra_args]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", [2, 5])
+def test_bench_line_for_two_ranks(config):
+    r = _bench_two_ranks({}, ("--config", str(config)) + (("--length", "200") if config == 5 else ()))
+    assert r["n_gpus"] == 2 and r["value"] > 0
+    strong = config == 5
+    assert r["scaling"] == ("strong" if strong else "weak")
+    assert r["config"]["subjects_total"] == (64000 if strong else 128000)
+    assert r["config"]["subjects_this_rank"] == (32000 if strong else 64000)
+    g = r["gather"]
+    assert "error" not in g, g
+    assert g["root_blocks_checked"] >= 3 and g["gcups_with_gather"] > 0
+    assert "cpu_baseline" not in r and "total_gcups" not in r       # rank 0 at N = 1 only
+
+
+def test_bench_line_survives_a_gather_that_never_finishes():
+    """An interconnect problem is a hang, not an exception: the watchdog prints the kernel-only line and every rank
+    leaves with exit code 0."""
+    r = _bench_two_ranks({"BGSA_BENCH_GATHER_TIMEOUT": "0.001"}, ("--config", "2"))
+    assert r["n_gpus"] == 2 and r["value"] > 0
+    assert "did not finish" in r["gather"]["error"]
