@@ -969,6 +969,9 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
             z0 = bx.op3(lambda a, _a, __a: ~a, planes[0], planes[0], planes[0], "z0")
         elif B == 2:
             z0 = bx.op3(lambda a, b_, _b: ~(a | b_), planes[0], planes[1], planes[1], "z0")
+        elif K > 1 and B > 3:
+            # u == 0 shares the "high planes are zero" product with the small-u masks below
+            z0 = bx.and_pattern(msb_first, [0] * B, "z")
         else:
             low = bx.or_all(planes[:B - 2], "lo") if B > 3 else planes[0]
             z0 = bx.op3(lambda a, b_, c: ~(a | b_ | c), low, planes[B - 2], planes[B - 1], "z0")   # u == 0
@@ -1033,8 +1036,9 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     # ---- w planes, v = max(0, w - u) = (w + ~u + 1) where that does not borrow, else 0 ------------------
     lit = {"reg": lambda x: x, "not": lambda x: ~x, "zero": lambda x: 0, "one": lambda x: 0xFF}
 
-    def subtract(w, minuend, sub_name, out_name):
-        """out = max(0, minuend - sub) over B planes; minuend[i] = (kind, register name or None)."""
+    def subtract(w, minuend, sub_name, out_name, top_out=None):
+        """out = max(0, minuend - sub) over B planes; minuend[i] = (kind, register name or None).  The top plane
+        comes out clamped (into `top_out` if given); the caller ANDs planes 0..B-2 with the returned mask."""
         carry = None
         for i in range(B):
             kind, name = minuend[i]
@@ -1046,11 +1050,19 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
                 else:
                     b.BITOP3(t(f"{out_name}{i}", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) ^ s)
                 carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) | ~s)
+            elif i == B - 1:
+                # top plane: its clamp (difference bit AND "no borrow out of this plane") is a function of the same three
+                # inputs, so it costs no instruction of its own
+                maj = lambda m, s, cy, f=f: (f(m) & ~s) | (f(m) & cy) | (~s & cy)
+                prev = carry
+                carry = b.BITOP3(t(f"{out_name}c{i}", w), src, sub_name(i), prev, maj)
+                b.BITOP3(top_out or t(f"{out_name}{i}", w), src, sub_name(i), prev,
+                         lambda m, s, cy, f=f, maj=maj: (f(m) ^ ~s ^ cy) & maj(m, s, cy))
             else:
                 b.BITOP3(t(f"{out_name}{i}", w), src, sub_name(i), carry, lambda m, s, cy, f=f: f(m) ^ ~s ^ cy)
                 carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), carry,
                                  lambda m, s, cy, f=f: (f(m) & ~s) | (f(m) & cy) | (~s & cy))
-        return carry     # 1 = no borrow: the difference is >= 0
+        return carry     # 1 = no borrow: the difference is >= 0; planes 0..B-2 still need their AND with it
 
     for w in W:
         bx = _Bool(b, f"w{w}")
@@ -1099,7 +1111,7 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
             else:
                 wplanes.append((kind, bx.or_all(masks, "wp")))
         ok = subtract(w, wplanes, lambda i, w=w: U(w, i), "s")
-        for i in range(B):
+        for i in range(B - 1 if B > 1 else B):
             b.AND(t(f"s{i}", w), t(f"s{i}", w), ok)
 
     # ---- max(W, u): C at a match, D at a mismatch with u <= D, else u -------------------------------
@@ -1118,8 +1130,9 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
 
     # ---- new u = max(0, max(W, u) - v_in) -------------------------------------------------------------
     for w in W:
-        ok = subtract(w, [("reg", t(f"g{i}", w)) for i in range(B)], lambda i, w=w: t(f"s{i}", w), "r")
-        for i in range(B):
+        ok = subtract(w, [("reg", t(f"g{i}", w)) for i in range(B)], lambda i, w=w: t(f"s{i}", w), "r",
+                      top_out=U(w, B - 1) if B > 1 else None)
+        for i in range(B - 1 if B > 1 else B):
             b.AND(U(w, i), t(f"r{i}", w), ok)
     # chains first, their wait states filled with independent work (no extra registers)
     return schedule(b, BITPAL_SCHEDULE_WINDOW) if BITPAL_SCHEDULE_WINDOW else b
