@@ -247,7 +247,7 @@ const char *bitpal_kernel_name(const BitpalSet *s, int word_num);
 
 // Widest subject (in words) the Myers kernels keep whole in registers; wider ones run as column blocks.
 int myers_max_plain_words();
-int myers_semi_max_plain_words();   // the same for semi-global scoring (resident Peq planes only)
+int myers_semi_max_plain_words();   // the same for semi-global scoring (resident Peq planes, then code planes up to 32 words)
 
 // long_kernels.hip: state-in-memory kernels for subjects beyond the register-resident limits (A/B only).
 // Myers beyond kMaxWords words: column blocks of the generated body, per-wave carry buffers.

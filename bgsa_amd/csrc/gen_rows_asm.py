@@ -35,6 +35,7 @@ MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24]  # Peq masks
 MYERS_PEQ_BLOCK_NW = [12, 14, 16, 18, 20]  # column blocks with resident Peq planes (20 words: 238 VGPRs; 22 would need 256)
 MYERS_PAIR_NW = [1, 2]  # two rows per stream token: the 10-20 VALU row cannot hide the scalar dispatch
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word
+MYERS_SEMI_PLANES_NW = [26, 28, 30, 32]  # semi-global beyond the resident Peq planes (24 words), up to 1024 bp
 MYERS_BLOCK_NW = [12, 14, 16, 18, 20, 22, 24, 26, 28]  # block widths of the > 1024 bp kernel (32 would need 256 VGPRs: 1 wave/SIMD)
 BITPAL_VGPR_BUDGET = 224        # state + masks + temporaries a plain BitPAl kernel may hold
 BITPAL_BLOCK_VGPR_BUDGET = 248  # a column-block kernel in total: two waves per SIMD need <= 256
@@ -904,6 +905,15 @@ def main() -> int:
                  "                                                      const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PLANES_NW:
         parts.append(gen_function("myers_planes_rows_asm", f"{nw}", R.myers_planes_body(nw), 2 * nw, 0, n_planes=3 * nw))
+    parts.append("\n// Semi-global on the code planes (subjects of 769..1024 bp): rows_ir.py: myers_semi_planes_body — the unused low\n"
+                 "// columns carry code 7, which matches every class; 11 VALU per word + 3 per row.\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ int myers_semi_planes_rows_asm(uint32_t (&state)[2 * NW + 2],\n"
+                 "                                                           const uint32_t (&B)[3 * NW],\n"
+                 "                                                           const unsigned long long stream, const int n_windows);\n")
+    for nw in MYERS_SEMI_PLANES_NW:
+        parts.append(gen_function("myers_semi_planes_rows_asm", f"{nw}", R.myers_semi_planes_body(nw), 2 * nw + 2, 0,
+                                  n_planes=3 * nw))
     parts.append("\n// One column block of a subject longer than 1024 bp (rows_ir.py:myers_block_body).  state =\n"
                  "// {VP, VN} x NW, carry-in words (add, HP, HN), carry-out words; voff = this lane's byte offset\n"
                  "// of the current 32-row chunk in the wave's carry buffer ([chunk][3][64] dwords at carry_base).\n"

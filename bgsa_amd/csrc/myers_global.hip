@@ -348,6 +348,66 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
     }
 }
 
+// Semi-global for subjects of 769..1024 bp: the code planes right-aligned like the Peq planes of myers_semi_asm_kernel;
+// the unused low columns get code 7 (all three planes set), which MATCH3's truth tables treat as "matches every
+// class" (rows_ir.py: myers_semi_planes_body) — 11 VALU per word + 3 per row, two waves per SIMD at NW = 32.
+template <int NW>
+__global__ __launch_bounds__(256) void myers_semi_planes_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
+    int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (group >= n_groups) return;
+    const int s_cols = 32 * NW - read_len, sq = s_cols >> 5, sr = s_cols & 31;
+
+    uint32_t Bp[3 * NW];
+    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+    {
+        const uint32_t *rc = g + static_cast<size_t>(1) * word_num * kLanes, *rg = g + static_cast<size_t>(2) * word_num * kLanes;
+        const uint32_t *rt = g + static_cast<size_t>(3) * word_num * kLanes, *rn = g + static_cast<size_t>(4) * word_num * kLanes;
+        uint32_t lo[3];   // source word (w - sq - 1) of the three code planes
+        {
+            const uint32_t t = semi_source_word(rt, word_num, -sq - 1);
+            lo[0] = semi_source_word(rc, word_num, -sq - 1) | t;
+            lo[1] = semi_source_word(rg, word_num, -sq - 1) | t;
+            lo[2] = semi_source_word(rn, word_num, -sq - 1);
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t t = semi_source_word(rt, word_num, w - sq);
+            const uint32_t hi[3] = {semi_source_word(rc, word_num, w - sq) | t, semi_source_word(rg, word_num, w - sq) | t,
+                                    semi_source_word(rn, word_num, w - sq)};
+            const uint32_t dummy = semi_dummy_mask(w, s_cols);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                Bp[3 * w + i] = semi_funnel(hi[i], lo[i], sr) | dummy;
+                lo[i] = hi[i];
+            }
+        }
+    }
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+    for (int q = q0; q < q1; q++) {
+        uint32_t st[2 * NW + 2];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            st[2 * w] = ~semi_dummy_mask(w, s_cols);
+            st[2 * w + 1] = 0u;
+        }
+        st[2 * NW] = st[2 * NW + 1] = static_cast<uint32_t>(read_len);
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        note_stream_fault(fault_word, myers_semi_planes_rows_asm<NW>(st, Bp, uniform_u64(s),
+                                                                     __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
+        dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(-static_cast<int>(st[2 * NW + 1]));
+    }
+}
+
 // Subjects longer than 1024 bp: column blocks of NW words.  For each query the wave runs the
 // generated row loop once per block; the three carry chains of row r cross the block boundary
 // through its carry buffer ([32-row chunk][add, HP, HN][lane] words in the workspace, first row in
@@ -565,7 +625,7 @@ int launch_semi_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_res
     return BGSA_HIP_OK;
 }
 
-template <int NW>
+template <int NW, bool SEMI = false>
 int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                   int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                   void *d_workspace, hipStream_t stream)
@@ -583,10 +643,16 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
     if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
-    hipLaunchKernelGGL((myers_global_planes_kernel<NW>), grid, dim3(256), 0, stream,
-                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
-                       read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
+    if constexpr (SEMI)
+        hipLaunchKernelGGL((myers_semi_planes_kernel<NW>), grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                           read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                           nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
+    else
+        hipLaunchKernelGGL((myers_global_planes_kernel<NW>), grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                           read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                           nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -708,8 +774,16 @@ int myers_peq_max_words()
     return limit;
 }
 
-// Semi-global: widest subject (words) scored by myers_semi_asm_kernel; wider ones run as column blocks.
-int myers_semi_max_plain_words() { return myers_peq_max_words(); }
+// Semi-global: widest subject (words) scored without column blocks — resident Peq planes (myers_semi_asm_kernel) up
+// to myers_peq_max_words(), the code planes (myers_semi_planes_kernel) up to 32 words; wider ones run as column blocks.
+int myers_semi_max_plain_words() { return 32; }
+
+int pick_semi_planes_nw(int word_num)
+{
+    for (int nw : {26, 28, 30, 32})
+        if (nw >= word_num) return nw;
+    return -1;
+}
 
 int pick_peq_nw(int word_num)
 {
@@ -727,8 +801,10 @@ const char *myers_kernel_name(int word_num, int semi_global)
         int n_blocks = 0;
         if (myers_impl() != 0)
             snprintf(name, sizeof name, "myers_global_kernel<%d, 1, true>", nw);
-        else if (word_num <= myers_semi_max_plain_words())
+        else if (word_num <= myers_peq_max_words())
             snprintf(name, sizeof name, "myers_semi_asm_kernel<%d>", pick_peq_nw(word_num));
+        else if (word_num <= myers_semi_max_plain_words())
+            snprintf(name, sizeof name, "myers_semi_planes_kernel<%d>", pick_semi_planes_nw(word_num));
         else
             snprintf(name, sizeof name, "myers_blocked_kernel<%d, true, true>", pick_peq_block_nw(word_num, &n_blocks));
         return name;
@@ -756,8 +832,19 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
     if (semi_global && myers_impl() == 0) {
-        // generated-asm kernels: resident Peq planes up to 24 words, column blocks (any length) beyond
-        if (word_num <= myers_semi_max_plain_words()) {
+        // generated-asm kernels: resident Peq planes up to 24 words, code planes up to 32, column blocks (any length) beyond
+        if (word_num > myers_peq_max_words() && word_num <= myers_semi_max_plain_words()) {
+            switch (pick_semi_planes_nw(word_num)) {
+#define BGSA_SEMI_PLANES_CASE(N)                                                                \
+    case N:                                                                                     \
+        return launch_planes<N, true>(d_content, d_peq, d_results, ref_len, read_len, read_count, \
+                                      ref_start, ref_end, word_num, d_workspace, stream);
+                BGSA_SEMI_PLANES_CASE(26) BGSA_SEMI_PLANES_CASE(28) BGSA_SEMI_PLANES_CASE(30) BGSA_SEMI_PLANES_CASE(32)
+#undef BGSA_SEMI_PLANES_CASE
+            default: break;
+            }
+        }
+        if (word_num <= myers_peq_max_words()) {
             switch (pick_peq_nw(word_num)) {
 #define BGSA_SEMI_CASE(N)                                                                       \
     case N:                                                                                     \

@@ -83,10 +83,13 @@ class Body:
     def LSHR1(self, d, a): return self._emit("lshr1", d, a)            # d = a >> 1 (slow class)
     def ALIGNBIT(self, d, hi, lo, sh): return self._emit("alignbit", d, hi, lo, sh)  # ({hi,lo} >> sh)[31:0], sh scalar
 
-    def MATCH3(self, d, b0, b1, b2):
+    def MATCH3(self, d, b0, b1, b2, wild=False):
         """d = columns whose 3-bit character code (b2 b1 b0) equals the row's class (0..4 = A C G T
-        N): a v_bitop3 whose truth table depends on which of the five body copies it sits in."""
-        tts = tuple(tt(lambda x0, x1, x2, c=c: (x0 if c & 1 else ~x0) & (x1 if c & 2 else ~x1) & (x2 if c & 4 else ~x2))
+        N): a v_bitop3 whose truth table depends on which of the five body copies it sits in.
+        wild: code 7, which no character has, matches every class (the semi-global kernels' unused low
+        columns) — still one instruction, only the truth tables differ."""
+        tts = tuple(tt(lambda x0, x1, x2, c=c: ((x0 if c & 1 else ~x0) & (x1 if c & 2 else ~x1) & (x2 if c & 4 else ~x2))
+                       | ((x0 & x1 & x2) if wild else 0))
                     for c in range(5))
         return self._emit("match3", d, b0, b1, b2, imm=tts)
 
@@ -468,6 +471,69 @@ def myers_planes_body(nw: int) -> Body:
         b.AND(M(w), D(w), HP(w))
         b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
     return b
+
+
+def myers_semi_planes_body(nw: int) -> Body:
+    """Semi-global Myers for subjects of 769..1024 bp: myers_planes_body with myers_semi_body's changes — HP shift
+    with carry-in 0, the subject right-aligned, the carries leaving the HP / HN chains accumulated into the running
+    last-column score — and the unused low columns coded 7 in the planes, the code that matches every class (MATCH3
+    wild), so they cost no instruction.  11 VALU per word + 3 per row.
+    State: S[2w] = VP, S[2w+1] = VN, S[2nw] = D[i][n], S[2nw+1] = its minimum so far."""
+    b = Body()
+    P = lambda w: f"S{w * 2}"
+    M = lambda w: f"S{w * 2 + 1}"
+    D = lambda w: f"d{w}"
+    HP = lambda w: f"hp{w}"
+    RUN, BEST = f"S{2 * nw}", f"S{2 * nw + 1}"
+    for w in range(nw):
+        b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}", wild=True)
+        b.AND(D(w), P(w), "e")
+        (b.ADD_CO if w == 0 else b.ADDC)(D(w), D(w), P(w))
+        b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
+        b.OR(D(w), D(w), "e")
+    for w in range(nw):  # HP chain, carry-in 0; HN parks in the VP register
+        b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
+        b.AND(P(w), D(w), P(w))
+        (b.ADD_CO if w == 0 else b.ADDC)(HP(w), HP(w), HP(w))
+    b.AND(M(0), D(0), HP(0))            # two instructions behind the chain's last link
+    b.AND(M(1), D(1), HP(1))
+    b.ADDCZ(RUN)                        # + the HP bit that left the last column
+    for w in range(nw):  # HN chain in place, then the new vertical deltas
+        (b.ADD_CO if w == 0 else b.ADDC)(P(w), P(w), P(w))
+        if w >= 2:
+            b.AND(M(w), D(w), HP(w))
+        b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
+    b.SUBBZ(RUN)                        # - the HN bit that left the last column
+    b.MINU(BEST, BEST, RUN)
+    return b
+
+
+def myers_semi_planes_simulate(subjects: np.ndarray, query: np.ndarray, nw: int) -> np.ndarray:
+    """One query against the subjects with myers_semi_planes_body, set up as myers_semi_planes_kernel<NW> does."""
+    n, slen = subjects.shape
+    wn = (slen + 31) // 32
+    peq = build_peq32(subjects, wn)
+    planes5 = [peq[1] | peq[3], peq[2] | peq[3], peq[4]]                 # [3][wn][n]
+    s = 32 * nw - slen
+    B, st = [], []
+    for w in range(nw):
+        lo_col = 32 * w - s
+        dummy = 0xFFFFFFFF if 32 * (w + 1) <= s else ((1 << (s - 32 * w)) - 1 if 32 * w < s else 0)
+        for i in range(3):
+            word = np.zeros(n, dtype=np.uint64)
+            for src in (lo_col // 32, lo_col // 32 + 1):
+                if 0 <= src < wn:
+                    shift = 32 * src - lo_col
+                    v = planes5[i][src].astype(np.uint64)
+                    word |= (v << np.uint64(shift)) if shift >= 0 else (v >> np.uint64(-shift))
+            B.append(((word & np.uint64(0xFFFFFFFF)) | np.uint64(dummy)).astype(np.uint32))
+        st += [np.full(n, ~dummy & 0xFFFFFFFF, np.uint32), np.zeros(n, np.uint32)]
+    st += [np.full(n, slen, np.uint32), np.full(n, slen, np.uint32)]
+    body = myers_semi_planes_body(nw)
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+    for ch in query:
+        body.simulate(st, [], cls=code.get(int(ch), 0), planes=B)
+    return (-st[2 * nw + 1].astype(np.int64)).astype(np.int16)
 
 
 def myers_block_body(nw: int) -> Body:
@@ -1217,7 +1283,7 @@ def bitpal_block_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT):
 
 def bitpal_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     """For the default scores this computes what the packed kernel of original/BGSA_AVX2/align_core.c:
-    183-428 computes (194 ALU operations per word there), on four unsigned planes, in 72 fast-class VALU."""
+    183-428 computes (194 ALU operations per word there), on four unsigned planes, in 69 fast-class VALU."""
     return bitpal_scores_body(nw, sc)
 
 

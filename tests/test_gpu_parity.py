@@ -694,7 +694,8 @@ def test_myers_positive_distance(oracle, slen):
 
 # ---- semi-global Myers (generator -m 0 -s): the subject end to end inside the query --------------------
 @pytest.mark.parametrize("qlen,slen", [(200, 60), (150, 150), (33, 97), (1, 1), (500, 250), (1000, 300), (700, 1000), (300, 1024),
-                                       (64, 32), (90, 33), (400, 768), (400, 769), (900, 800), (1300, 1100), (3000, 2500), (200, 4000)])
+                                       (64, 32), (90, 33), (400, 768), (400, 769), (900, 800), (1300, 1100), (3000, 2500), (200, 4000),
+                                       (900, 832), (850, 833), (1000, 900), (990, 961), (1100, 1023), (120, 1000)])
 def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
     q = oracle.gen_reads(600 + qlen, 4, qlen)
     s = oracle.gen_reads(700 + slen, 130, slen)
@@ -712,14 +713,16 @@ def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
 
 
 def test_myers_semiglobal_kernel_families(oracle):
-    # generated-asm kernels: resident Peq planes up to 768 bp, column blocks of the same body beyond — any length
+    # generated-asm kernels: resident Peq planes up to 768 bp, code planes up to 1024 bp, column blocks beyond — any length
     L = B.lib()
     L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
     L.bgsa_hip_select_alignment(1)
     try:
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 5).startswith(b"myers_semi_asm_kernel<5>")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 24).startswith(b"myers_semi_asm_kernel<24>")
-        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 32).startswith(b"myers_blocked_kernel<16, true, true>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 25).startswith(b"myers_semi_planes_kernel<26>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 32).startswith(b"myers_semi_planes_kernel<32>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 33).startswith(b"myers_blocked_kernel<")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 125).startswith(b"myers_blocked_kernel<18, true, true>")
     finally:
         L.bgsa_hip_select_alignment(0)

@@ -57,6 +57,26 @@ def test_myers_semi_body_matches_the_dp(oracle, qlen, slen, nw):
     assert R.count_hazard_nops(R.myers_semi_body(nw)) <= 2      # two wait states per row, of 10 nw + 3 instructions
 
 
+@pytest.mark.parametrize("qlen,slen,nw", [(900, 800, 26), (70, 769, 26), (1100, 1024, 32), (400, 1000, 32), (300, 833, 28),
+                                         (200, 930, 30), (64, 40, 2), (150, 150, 6)])
+def test_myers_semi_planes_body_matches_the_dp(oracle, qlen, slen, nw):
+    """The code-plane form of the semi-global body (subjects of 769..1024 bp): the unused low columns are coded 7,
+    the code that matches every class, instead of being ORed into five masks."""
+    q = oracle.gen_reads(2800 + qlen, 2, qlen)
+    s = oracle.gen_reads(2900 + slen, 24, slen)
+    if qlen >= slen:
+        for r in range(8):
+            off = (r * 17) % (qlen - slen + 1)
+            s[r] = oracle.mutate(q[r % 2: r % 2 + 1, off:off + slen], [r % 6], 3000 + r)[0]
+    s[3, : slen // 2] = ord("N")
+    q[1, 5:9] = ord("N")
+    want = oracle.dp_edit_semiglobal(q, s)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.myers_semi_planes_simulate(s, q[i], nw), want[i])
+    body = R.myers_semi_planes_body(nw)
+    assert body.valu_count() == 11 * nw + 3 and R.count_hazard_nops(body) <= 2
+
+
 @pytest.mark.parametrize("qlen,slen", [(300, 300), (150, 150), (90, 257)])
 def test_myers_planes_body_matches_oracle(oracle, qlen, slen):
     q, s = _inputs(oracle, 1500 + slen, 2, 40, qlen, slen)
