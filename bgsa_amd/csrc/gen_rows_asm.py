@@ -288,9 +288,11 @@ def gen_banded_function(wide: bool) -> str:
             if name.startswith("E"):
                 return f"%[m{name[1:]}_{c}]"
             if name in ("$mask", "$mask_lo"):
-                return S_MASK
+                # the band mask lives in a VGPR: a three-source VOP3 with an SGPR source issues in the half-rate class
+                # (scripts/ubench: k3_sgpr 4.4 cycles against 2.7-2.95 with three VGPRs)
+                return "%[vmask]"
             if name == "$mask_hi":
-                return S_MASK_HI
+                return "%[vmask_hi]"
             if name == "$sh":
                 return S_SH
             if name == "$one":
@@ -318,8 +320,6 @@ def gen_banded_function(wide: bool) -> str:
         f"s_mov_b32 {S_LEFT}, %[nwin]",
         f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
         f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
-        f"s_mov_b32 {S_MASK}, %[mask]",
-        f"s_mov_b32 {S_MASK_HI}, %[mask_hi]",
         f"s_mov_b32 {S_THR}, %[thr]",
         f"s_mov_b32 {S_SH}, 0",
         f"s_mov_b64 {S_DEAD}, 0",
@@ -451,8 +451,8 @@ def gen_banded_function(wide: bool) -> str:
     outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(n_m)]
     outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)', '[left] "=s"(left)', '[early] "=s"(early)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[mask] "s"(band_mask)', '[mask_hi] "s"(band_mask_hi)',
-           '[thr] "s"(limit)', '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
+    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[vmask] "v"(band_mask)'] + (['[vmask_hi] "v"(band_mask_hi)'] if wide else []) + \
+          ['[thr] "s"(limit)', '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
     clob = ", ".join(f'"{x}"' for x in clobbers)
     return f"""
@@ -665,7 +665,7 @@ def gen_banded_chunk_function() -> str:
     outs += [f'[next{c}] "=&v"(nxt[{c}])' for c in range(5)]
     outs += ['[vaddr] "=&v"(vaddr)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = ['[lanebase] "v"(lanebase)', '[tokbase] "s"(tokens)', '[gbase] "s"(gbase)', '[mask] "s"(band_mask)', '[thr] "s"(limit)',
+    ins = ['[lanebase] "v"(lanebase)', '[tokbase] "s"(tokens)', '[gbase] "s"(gbase)', '[mask] "v"(band_mask)', '[thr] "s"(limit)',
            '[k] "s"(k)', '[last] "s"(last)', '[len] "s"(len)', '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
     clob = ", ".join(f'"{x}"' for x in clobbers)
     return f"""
