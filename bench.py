@@ -101,6 +101,8 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
     if algo == B.ALGO_BITPAL and wn <= 8:
         return R.bitpal_body(wn, R.BitpalScores(*scores) if scores else R.BITPAL_DEFAULT).valu_count()
     if algo == B.ALGO_BANDED:                  # per row that is actually run (early exit: fewer rows than nominal)
+        if k <= 15 and R.banded_phase_rows(k) and os.environ.get("BGSA_BANDED_IMPL", "")[:1] == "p":
+            return R.banded_phase_body().valu_count()     # the band held in place (A/B alternative, k <= 11)
         return (R.banded_body() if k <= 15 else R.banded_body64()).valu_count()
     return None
 

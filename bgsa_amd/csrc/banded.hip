@@ -232,13 +232,17 @@ __device__ __forceinline__ void banded_finish_pair(uint32_t entry, const uint32_
 // The whole query runs inside one generated asm block — 12 VALU per row for k <= 15 (32-bit band
 // word), 22 for k <= 31 (64-bit pair) — with the window advance / checkpoints / early exit driven by
 // EVENT tokens of the packed stream (bgsa_common.h: banded_stream_layout).
-template <bool WIDE>
+// PHASE (BGSA_BANDED_IMPL=p; k <= 11, 32-bit band only; measured slower, kept as the A/B alternative): the band held
+// in place for `phase` = banded_phase_rows(k) rows at a time (rows_ir.py: banded_phase_body) — 13 fast-class VALU per
+// row, no half-rate instruction in the row, but a re-anchoring event per phase.
+template <bool WIDE, bool PHASE = false>
 __global__ __launch_bounds__(256) void banded_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
     unsigned *__restrict__ fault_word, const char *__restrict__ content, int ref_start, int len,
-    uint32_t push_row, uint32_t push_max)
+    uint32_t push_row, uint32_t push_max, int phase)
 {
+    static_assert(!(WIDE && PHASE), "the band is held in place in the 32-bit word only");
     // survivors of this wave's query tile waiting for their dense pass: (query - q0) << 8 | lane
     __shared__ uint32_t s_regroup[kWavesPerBlock][kLanes];
     uint32_t *regroup = s_regroup[threadIdx.x >> 6];
@@ -282,9 +286,10 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
             n_regroup = 0;
         }
         if (q == q1) break;
-        uint32_t st[WIDE ? 5 : 3];
+        constexpr int NS = PHASE ? 6 : (WIDE ? 5 : 3);
+        uint32_t st[NS];
 #pragma unroll
-        for (int i = 0; i < (WIDE ? 5 : 3); i++) st[i] = 0u;
+        for (int i = 0; i < NS; i++) st[i] = 0u;
         uint32_t M[kChars][NM];
 #pragma unroll
         for (int c = 0; c < kChars; c++)
@@ -304,6 +309,19 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
             vp = st[0] | (static_cast<unsigned long long>(st[1]) << 32);
             vn = st[2] | (static_cast<unsigned long long>(st[3]) << 32);
             acc = st[4];
+        } else if constexpr (PHASE) {
+            st[3] = static_cast<uint32_t>(band);   // the band mask at offset 0
+            st[4] = 1u;                            // its lowest bit: the diagonal the errors are counted on
+            uint32_t W[kChars];                    // row 0: the window is the first word itself
+#pragma unroll
+            for (int c = 0; c < kChars; c++) W[c] = first[c][0];
+            dead_mask = banded_rows_phase_asm32(st, W, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band),
+                                                static_cast<uint32_t>(phase), limit, push_row, push_max, left, early);
+            // the state sits at the offset of the rows of the last phase; that phase's error bits are still uncounted
+            const int final_shift = len - phase * ((len - 1) / phase);
+            vp = st[0] >> final_shift;
+            vn = st[1] >> final_shift;
+            acc = st[2] + static_cast<uint32_t>(__popc(st[5]));
         } else {
             dead_mask = banded_rows_asm32(st, M, voff, base, uniform_u64(s), n_windows, static_cast<uint32_t>(band), 0u, limit,
                                           push_row, push_max, left, early);
@@ -477,7 +495,8 @@ int banded_push_row_offset()
     return v;
 }
 
-// 0 = generated asm, threaded row loop (default), 1 = compiler-scheduled C++ kernel (BGSA_BANDED_IMPL=c),
+// 0 = generated asm, threaded row loop, sliding band (default), 3 = the same loop with the band held in place for
+// k <= 11 (BGSA_BANDED_IMPL=p: measured 4-17 % slower, see rows_ir.py: banded_phase_body), 1 = compiler-scheduled C++ kernel (BGSA_BANDED_IMPL=c),
 // 2 = generated asm, straight-line chunk rows for k <= 15 (BGSA_BANDED_IMPL=s).  The straight-line kernel removes the
 // scalar work per row (7.85 SALU per wave-row in the threaded loop, on a scalar unit shared by the CU's four SIMDs) at
 // the price of one more VALU, two LDS reads per row and a slot rotation every 32 rows; measured on 10k x 1M x 150 bp,
@@ -488,7 +507,7 @@ int banded_impl()
 {
     static const int impl = [] {
         const char *e = getenv("BGSA_BANDED_IMPL");
-        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 's') ? 2 : 0);
+        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 's') ? 2 : ((e && e[0] == 'p') ? 3 : 0));
     }();
     return impl;
 }
@@ -526,8 +545,9 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     const int64_t n_groups = read_count / kLanes;
     int q_tile = 32;
     while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
-    if (int rc = launch_pack_banded(d_content, len, k, ref_start, ref_end, d_workspace, stream)) return rc;
-    const int stride = banded_stream_layout(len, k, nullptr, nullptr);
+    const int phase = banded_stream_phase(k);
+    if (int rc = launch_pack_banded(d_content, len, k, phase, ref_start, ref_end, d_workspace, stream)) return rc;
+    const int stride = banded_stream_layout(len, k, phase, nullptr, nullptr);
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kBandedRefill, 40, stream, &fault)) return rc;
 
@@ -539,16 +559,21 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     }
     const uint32_t push_row = static_cast<uint32_t>(k + banded_push_row_offset());
     const uint32_t push_max = static_cast<uint32_t>(banded_push_max());
-    if (k <= 15)
-        hipLaunchKernelGGL(banded_asm_kernel<false>, grid, dim3(256), 0, stream,
+    if (phase > 0)
+        hipLaunchKernelGGL((banded_asm_kernel<false, true>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
-                           fault, d_content, ref_start, len, push_row, push_max);
+                           fault, d_content, ref_start, len, push_row, push_max, phase);
+    else if (k <= 15)
+        hipLaunchKernelGGL((banded_asm_kernel<false, false>), grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
+                           fault, d_content, ref_start, len, push_row, push_max, 0);
     else
-        hipLaunchKernelGGL(banded_asm_kernel<true>, grid, dim3(256), 0, stream,
+        hipLaunchKernelGGL((banded_asm_kernel<true, false>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
-                           fault, d_content, ref_start, len, push_row, push_max);
+                           fault, d_content, ref_start, len, push_row, push_max, 0);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -578,12 +603,18 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
 
 static thread_local int g_last_k = 8;  // threshold of this thread's last banded launch
 
+int banded_stream_phase(int k)
+{
+    return (banded_impl() == 3 && k >= 1 && k <= 15) ? banded_phase_rows(k) : 0;
+}
+
 const char *banded_kernel_name(int word_num)
 {
     (void)word_num;
     if (banded_impl() == 1) return g_last_k <= 15 ? "banded_kernel<uint32_t>" : "banded_kernel<uint64_t>";
     if (banded_impl() == 2 && g_last_k <= 15) return "banded_chunk_kernel";
-    return g_last_k <= 15 ? "banded_asm_kernel<false>" : "banded_asm_kernel<true>";
+    if (banded_stream_phase(g_last_k) > 0) return "banded_asm_kernel<false, true>";
+    return g_last_k <= 15 ? "banded_asm_kernel<false, false>" : "banded_asm_kernel<true, false>";
 }
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,
@@ -603,7 +634,7 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
     if (banded_impl() == 2 && k <= 15)
         return launch_chunk(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                             d_workspace, stream);
-    if (banded_impl() != 1)
+    if (banded_impl() != 1)   // 0 and 3: the threaded loop
         return launch_asm(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                           d_workspace, stream);
     if (k <= 15)

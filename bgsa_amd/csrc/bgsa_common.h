@@ -114,14 +114,28 @@ constexpr int kBandedSingle = kPairSingle, kBandedEnd = kPairEnd, kBandedRefill 
 // testing more often rejects exactly the same pairs, only sooner.
 constexpr int kBandedCheckRows = 8;
 constexpr int kBandedLateRows = 48;   // from row k + 48 on the tests come every 16 rows
+// Rows a 32-bit word can hold the band of threshold k in place (rows_ir.py: banded_phase_body): its 2k + 1 bits start
+// at bit 0 and move up one bit per row; the bit above them must still exist in the phase's last row.  0: no room worth
+// a phase (k > 11) — those thresholds run the sliding form.
+constexpr int kBandedPhaseMin = 8;
+__host__ __device__ inline int banded_phase_rows(int k)
+{
+    const int rows = 31 - 2 * k;
+    return rows >= kBandedPhaseMin ? rows : 0;
+}
+int banded_stream_phase(int k);   // banded.hip: the phase length the kernel launched for threshold k uses (0: sliding form)
 inline size_t banded_stream_bound(int len)
 {
-    const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 + 4;
+    const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 +
+                          static_cast<size_t>(len) / kBandedPhaseMin + 4;
     const size_t threaded = (static_cast<size_t>(len) + 3 * events + 1 + 6) / 7 * 8 + 16;
     const size_t chunk_tokens = (static_cast<size_t>(len) + 31) / 32 * 32 * 4;   // banded_chunk_kernel: one dword per row
     return threaded > chunk_tokens ? threaded : chunk_tokens;
 }
-__host__ __device__ inline int banded_stream_layout(int len, int k, const char *row, unsigned char *dst)
+// EVENT bits: 1 = scoring starts (row k), 2 = next 32 rows (the match-string words move down), 4 = test the error
+// limit, 8 = latch the reject mask (the reference's last checkpoint), 16 = re-anchor the band (every `phase` rows;
+// phase = 0: the sliding form, no such event).
+__host__ __device__ inline int banded_stream_layout(int len, int k, int phase, const char *row, unsigned char *dst)
 {
     const int last = (len <= 64) ? len : ((len - k > 64) ? len - k : 64);
     int pos = 0, slot = 0, pending = 0;
@@ -149,7 +163,9 @@ __host__ __device__ inline int banded_stream_layout(int len, int k, const char *
         return c > 4 ? 0 : c;
     };
     // events due before row r starts / after `done` rows are complete
-    auto before = [&](int r) { return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0); };
+    auto before = [&](int r) {
+        return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0) | ((phase > 0 && r > 0 && r % phase == 0) ? 16 : 0);
+    };
     // Tests between checkpoints only decide how soon a wave may stop, never the result (the errors are monotone and
     // the reject mask is latched at `last`): none before a lane can be past the limit at all (more than k + 1 errors
     // need more than k + 1 scored rows), every kBandedCheckRows rows while random pairs are dying, every
@@ -214,7 +230,7 @@ __host__ __device__ inline int blocked_stream_layout(int len, const char *row, u
 int launch_pack_blocked(const char *d_content, int len, int ref_start, int ref_end, void *d_streams,
                         hipStream_t stream);
 
-int launch_pack_banded(const char *d_content, int len, int k, int ref_start, int ref_end, void *d_streams,
+int launch_pack_banded(const char *d_content, int len, int k, int phase, int ref_start, int ref_end, void *d_streams,
                        hipStream_t stream);
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,

@@ -653,8 +653,9 @@ int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, 
 {
     if (!mapped_row || ref_len <= 0) return BGSA_HIP_EINVAL;
     if (algo == BGSA_ALGO_BANDED) {
-        const int n = banded_stream_layout(ref_len, k, nullptr, nullptr);
-        if (dst && cap >= n) banded_stream_layout(ref_len, k, mapped_row, dst);
+        const int phase = banded_stream_phase(k);
+        const int n = banded_stream_layout(ref_len, k, phase, nullptr, nullptr);
+        if (dst && cap >= n) banded_stream_layout(ref_len, k, phase, mapped_row, dst);
         return n;
     }
     if (algo == BGSA_ALGO_MYERS && k == -2) {  // the two-rows-per-token stream (subjects <= 64 bp)

@@ -262,17 +262,21 @@ __device__ __forceinline__ int {fn_name}<{template_args}>(uint32_t (&state)[{n_s
 """
 
 
-def gen_banded_function(wide: bool) -> str:
+def gen_banded_function(wide: bool, phase: bool = False) -> str:
     """Row loop of the banded kernel: 32-bit band word (k <= 15) or a 64-bit pair (k <= 31).  Same
     threaded-code skeleton plus stream code 63 = EVENT (followed by an argument byte): test/latch the
     reject mask, reset the error count at row k, advance the match-string words every 32 rows
-    (rows_ir.banded_tokens)."""
-    body = R.banded_body64() if wide else R.banded_body()
-    n_state = 5 if wide else 3          # the error count is the last state register
+    (rows_ir.banded_tokens).  phase: the band held in place (rows_ir.banded_phase_body, k <= 11) — the rows read
+    the phase's window of their class (W[c]) and a re-anchor event (bit 16) every banded_phase_rows(k) rows shifts
+    the state back down, folds the collected error bits and cuts the next windows."""
+    assert not (wide and phase)
+    body = R.banded_phase_body() if phase else (R.banded_body64() if wide else R.banded_body())
+    n_state = 6 if phase else (5 if wide else 3)   # VP, VN (lo/hi when wide), errors; phase: + band mask, its low bit, error bits
     n_m = 4 if wide else 3              # resident match-string words per class (last = prefetch target)
-    acc = n_state - 1
+    acc = 2 if phase else n_state - 1   # the error count
     slot_of, n_slots = body.allocate_temps()
-    S_MASK, S_SH, S_ARG, S_THR, S_MASK_HI = "s72", "s73", "s74", "s78", "s75"
+    S_SH, S_ARG, S_THR = "s73", "s74", "s78"
+    S_PH, S_MASK0 = "s72", "s75"       # phase only: rows per phase, the band mask at offset 0
     S_DEAD, S_TMP = "s[76:77]", "s[90:91]"
     S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
     # survivor compaction (banded.hip "survivor queue"): rows done = 32 * S_CHUNK + S_SH; a test at or after row
@@ -286,7 +290,7 @@ def gen_banded_function(wide: bool) -> str:
             if name.startswith("S"):
                 return f"%[s{name[1:]}]"
             if name.startswith("E"):
-                return f"%[m{name[1:]}_{c}]"
+                return f"%[w{c}]" if phase else f"%[m{name[1:]}_{c}]"
             if name in ("$mask", "$mask_lo"):
                 # the band mask lives in a VGPR: a three-source VOP3 with an SGPR source issues in the half-rate class
                 # (scripts/ubench: k3_sgpr 4.4 cycles against 2.7-2.95 with three VGPRs)
@@ -321,6 +325,7 @@ def gen_banded_function(wide: bool) -> str:
         f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
         f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
         f"s_mov_b32 {S_THR}, %[thr]",
+    ] + ([f"s_mov_b32 {S_PH}, %[phase]", f"s_mov_b32 {S_MASK0}, %[mask0]"] if phase else []) + [
         f"s_mov_b32 {S_SH}, 0",
         f"s_mov_b64 {S_DEAD}, 0",
         f"s_mov_b32 {S_CHUNK}, 0",
@@ -381,7 +386,8 @@ def gen_banded_function(wide: bool) -> str:
         # by far the most frequent event is the plain test (argument 4): its own short path, no bit tests
         f"s_cmp_eq_u32 {S_ARG}, 4",
         "s_cbranch_scc0 L_ev_general_%=",
-        f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc}]",
+    ] + ([f"v_bcnt_u32_b32 %[t0], %[s5], %[s{acc}]", f"v_cmp_lt_u32 vcc, {S_THR}, %[t0]"] if phase else
+         [f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc}]"]) + [
         f"s_andn2_b64 {S_TMP}, exec, vcc",
         "s_cbranch_scc0 L_ev_alldead_%=",
         f"s_lshl_b32 {S_CNT}, {S_CHUNK}, 5",
@@ -401,7 +407,8 @@ def gen_banded_function(wide: bool) -> str:
         # bit 2: test err > limit on every lane; bit 3: latch the reject mask (last checkpoint)
         f"s_bitcmp1_b32 {S_ARG}, 2",
         "s_cbranch_scc0 L_ev_reset_%=",
-        f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc}]",
+    ] + ([f"v_bcnt_u32_b32 %[t0], %[s5], %[s{acc}]", f"v_cmp_lt_u32 vcc, {S_THR}, %[t0]"] if phase else
+         [f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc}]"]) + [
         f"s_bitcmp1_b32 {S_ARG}, 3",
         "s_cbranch_scc0 L_ev_all_%=",
         f"s_mov_b64 {S_DEAD}, vcc",
@@ -426,9 +433,10 @@ def gen_banded_function(wide: bool) -> str:
         f"s_bitcmp1_b32 {S_ARG}, 0",      # bit 0: scoring starts (row k)
         "s_cbranch_scc0 L_ev_adv_%=",
         f"v_mov_b32 %[s{acc}], 0",
+    ] + (["v_mov_b32 %[s5], 0"] if phase else []) + [
         "L_ev_adv_%=:",
         f"s_bitcmp1_b32 {S_ARG}, 1",      # bit 1: next 32 rows -> shift the match-string words down
-        "s_cbranch_scc0 L_ev_out_%=",
+        "s_cbranch_scc0 L_ev_anchor_%=",
         "s_waitcnt vmcnt(0)",
     ]
     for c in range(5):
@@ -439,6 +447,21 @@ def gen_banded_function(wide: bool) -> str:
         "v_add_u32 %[voff], 0x100, %[voff]",
         f"s_mov_b32 {S_SH}, 0",
         f"s_add_u32 {S_CHUNK}, {S_CHUNK}, 1",
+        "L_ev_anchor_%=:",
+    ]
+    if phase:
+        asm += [
+            f"s_bitcmp1_b32 {S_ARG}, 4",  # bit 4: the phase is over -> the band back to bit 0, its error bits counted, new windows
+            "s_cbranch_scc0 L_ev_out_%=",
+            f"v_lshrrev_b32 %[s0], {S_PH}, %[s0]",
+            f"v_lshrrev_b32 %[s1], {S_PH}, %[s1]",
+            f"v_bcnt_u32_b32 %[s{acc}], %[s5], %[s{acc}]",
+            "v_mov_b32 %[s5], 0",
+            f"v_mov_b32 %[s3], {S_MASK0}",
+            "v_mov_b32 %[s4], 1",
+        ]
+        asm += [f"v_alignbit_b32 %[w{c}], %[m1_{c}], %[m0_{c}], {S_SH}" for c in range(5)]
+    asm += [
         "L_ev_out_%=:",
     ]
     asm += disp()
@@ -449,12 +472,23 @@ def gen_banded_function(wide: bool) -> str:
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
     outs += [f'[m{w}_{c}] "+v"(M[{c}][{w}])' for c in range(5) for w in range(n_m)]
+    if phase:
+        outs += [f'[w{c}] "+v"(W[{c}])' for c in range(5)]
     outs += ['[voff] "+v"(voff)', '[dead] "=s"(dead)', '[left] "=s"(left)', '[early] "=s"(early)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[vmask] "v"(band_mask)'] + (['[vmask_hi] "v"(band_mask_hi)'] if wide else []) + \
+    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)'] + \
+          (['[phase] "s"(phase_rows)', '[mask0] "s"(band_mask)'] if phase else ['[vmask] "v"(band_mask)']) + \
+          (['[vmask_hi] "v"(band_mask_hi)'] if wide else []) + \
           ['[thr] "s"(limit)', '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
     clob = ", ".join(f'"{x}"' for x in clobbers)
+    fn_name = "banded_rows_phase_asm32" if phase else f"banded_rows_asm{64 if wide else 32}"
+    w_param = "uint32_t (&W)[5], " if phase else ""
+    last_param = "phase_rows" if phase else "band_mask_hi"
+    phase_doc = ("// The band held in place: state = {VP, VN, errors before this phase, band mask at the row's offset, its lowest bit,\n"
+                 "// the phase's error bits}; W[c] = the phase's match window of class c; phase_rows = banded_phase_rows(k).  After the\n"
+                 "// loop the state sits at the offset of the rows of the LAST phase: the caller shifts VP / VN down by that and adds\n"
+                 "// popcount(error bits) to the errors.\n") if phase else ""
     return f"""
 // {body.valu_count()} VALU per row ({sum(op.kind in ('lshr1', 'alignbit') for op in body.ops)} of them slow-class), {n_slots} temporaries
 // state = {{VP, VN, errors since row k}} (VP lo/hi, VN lo/hi, errors when wide); M[c][..] = consecutive
@@ -464,10 +498,10 @@ def gen_banded_function(wide: bool) -> str:
 // stream's remaining window budget, negative after a malformed stream (gen_rows_asm.py: S_LEFT).
 // early = 1: a test at or after row push_row found 1..push_max lanes within the limit and the wave stopped
 // there; the returned mask then holds the lanes past the limit, the others go to the survivor queue.
-__device__ __forceinline__ unsigned long long banded_rows_asm{64 if wide else 32}(uint32_t (&state)[{n_state}], uint32_t (&M)[5][{n_m}], uint32_t &voff,
+{phase_doc}__device__ __forceinline__ unsigned long long {fn_name}(uint32_t (&state)[{n_state}], {w_param}uint32_t (&M)[5][{n_m}], uint32_t &voff,
                                                               const unsigned long long (&base)[5],
                                                               const unsigned long long stream, const int n_windows,
-                                                              const uint32_t band_mask, const uint32_t band_mask_hi,
+                                                              const uint32_t band_mask, const uint32_t {last_param},
                                                               const uint32_t limit, const uint32_t push_row,
                                                               const uint32_t push_max, int &left, int &early)
 {{
@@ -935,7 +969,7 @@ def main() -> int:
     # ---- BitPAl, default scores (other score sets: gen_bitpal_sets.py) ------------------------
     (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))
     # ---- banded -------------------------------------------------------------------------------
-    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(True) +
+    (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(False, phase=True) + gen_banded_function(True) +
                                               gen_banded_chunk_function())
     return 0
 

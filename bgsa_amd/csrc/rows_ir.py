@@ -713,6 +713,48 @@ def banded_body64() -> Body:
     return b
 
 
+BANDED_PHASE_MIN = 8   # bgsa_common.h: kBandedPhaseMin
+
+
+def banded_phase_rows(k: int) -> int:
+    """Rows a 32-bit word can hold the band of threshold k IN PLACE (bgsa_common.h: banded_phase_rows): the band's
+    2k + 1 bits start at bit 0, move up one bit per row, and the bit above them must still exist in the phase's last
+    row.  0 = no room worth using (k > 11): those thresholds run the sliding form (banded_body)."""
+    rows = 31 - 2 * k
+    return rows if rows >= BANDED_PHASE_MIN else 0
+
+
+def banded_phase_body() -> Body:
+    """The band held in place (k <= 11; BGSA_BANDED_IMPL=p, measured and NOT the default): for banded_phase_rows(k) rows
+    the match window of each class is fixed (E0 = the phase's window of the row's class, one funnel shift per class
+    and PHASE instead of one per row) and the band moves up one bit per row inside the register, which is the
+    classical recurrence — HP and HN move left through x + x, fast class — instead of the sliding one (D0 >> 1,
+    half-rate class).  Every instruction of the row is fast class, and the row alone is ≈ 7 % faster than
+    banded_body's; but every phase ends with a re-anchoring event (two shifts, a popcount, five funnel shifts — all
+    half-rate — plus the event's scalar path) that costs as much as 2.6 rows, so at k = 8 (15 rows per phase) the
+    loop is 8 % SLOWER than the sliding form, and still 4 % slower at k = 2 (27 rows per phase).  DESIGN.md §4.4.
+    State: S0 = VP, S1 = VN (at the row's offset), S2 = errors counted before this phase (since row k), S3 = the band
+    mask at the row's offset, S4 = its lowest bit, S5 = the phase's error bits: ~D0 on the lowest diagonal, one bit
+    per row (errors so far = S2 + popcount(S5)).  Bits outside the band hold no information: below it the masked
+    match word generates no carry, above it only the first bit is read and it is the band's carry-out whatever VP
+    holds there."""
+    b = Body()
+    b.BITOP3("x", "E0", "S1", "S3", lambda w, vn, m: (w | vn) & m)
+    b.AND("t", "x", "S0")
+    b.ADD("t", "t", "S0")
+    b.BITOP3("d0", "t", "S0", "x", lambda t, vp, x: (t ^ vp) | x)
+    b.BITOP3("hp", "d0", "S0", "S1", lambda d, vp, vn: ~(d | vp) | vn)
+    b.AND("hn", "d0", "S0")
+    b.ADD("hp", "hp", "hp")
+    b.ADD("hn", "hn", "hn")
+    b.AND("S1", "d0", "hp")
+    b.BITOP3("S0", "d0", "hp", "hn", lambda d, hp, hn: ~(d | hp) | hn)
+    b.BITOP3("S5", "S5", "d0", "S4", lambda a, d, sel: a | (~d & sel))
+    b.ADD("S3", "S3", "S3")
+    b.ADD("S4", "S4", "S4")
+    return b
+
+
 def banded_last_check(length: int, k: int) -> int:
     """Rows after which the reference runs its last err > max_err test (banded.hip)."""
     h = k
@@ -723,11 +765,12 @@ BANDED_CHECK_ROWS = 8   # bgsa_common.h: kBandedCheckRows
 BANDED_LATE_ROWS = 48   # bgsa_common.h: kBandedLateRows
 
 
-def banded_tokens(length: int, k: int, word_bits: int = 32):
+def banded_tokens(length: int, k: int, word_bits: int = 32, phase: int = 0):
     """The per-query token sequence of the banded stream, query characters as ('row', r):
     ('event', bits) with bits 1 = reset the error count (row k), 2 = advance the match-string
     words (every word_bits rows), 4 = test err > limit on all lanes, 8 = latch the reject mask
-    (the reference's last checkpoint).  Mirrors banded_stream_layout() in preprocess.hip."""
+    (the reference's last checkpoint), 16 = re-anchor the band (every `phase` rows; 0, the default: the sliding
+    form, no such event).  Mirrors banded_stream_layout() in bgsa_common.h."""
     last = banded_last_check(length, k)
     out, pending = [], 0
     for r in range(length):
@@ -735,6 +778,8 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
             pending |= 1
         if r > 0 and r % word_bits == 0:
             pending |= 2
+        if phase and r > 0 and r % phase == 0:
+            pending |= 16
         if pending:
             out.append(("event", pending))
             pending = 0
@@ -754,7 +799,7 @@ def banded_tokens(length: int, k: int, word_bits: int = 32):
 BANDED_SINGLE, BANDED_END, BANDED_REFILL, BANDED_EVENT = 25, 30, 31, 63
 
 
-def banded_stream_bytes(length: int, k: int, codes) -> list:
+def banded_stream_bytes(length: int, k: int, codes, phase: int = 0) -> list:
     """The packed banded stream, byte for byte as bgsa_common.h: banded_stream_layout() writes it:
     banded_tokens() with two consecutive rows folded into one token (5*a + b) wherever no event sits
     between them, one-row tokens 25 + c otherwise, EVENT = {63, bits}, 7 payload bytes + REFILL per
@@ -777,7 +822,7 @@ def banded_stream_bytes(length: int, k: int, codes) -> list:
         put(BANDED_EVENT)
         put(bits)
 
-    toks = banded_tokens(length, k)
+    toks = banded_tokens(length, k, phase=phase)
     i = 0
     while i < len(toks):
         kind, val = toks[i]
@@ -797,7 +842,8 @@ def banded_stream_bytes(length: int, k: int, codes) -> list:
     return out
 
 
-def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool | None = None) -> np.ndarray:
+def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool | None = None,
+                    phase: int = 0) -> np.ndarray:
     """Whole banded pipeline on the CPU with the shipped row body: Mext preprocess, token
     stream, events, final band walk.  Returns int8 results like the kernel.  wide = the 64-bit
     band body (register pairs), the default for k > 15."""
@@ -805,6 +851,8 @@ def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool 
         wide = k > 15
     if wide:
         return _banded_simulate64(subjects, query, k)
+    if phase:
+        return _banded_simulate_phase(subjects, query, k, phase)
     n, length = subjects.shape
     code = np.zeros(256, dtype=np.uint8)
     for ch, c in zip(b"ACGTN", range(5)):
@@ -823,7 +871,7 @@ def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool 
     dead = np.zeros(n, dtype=bool)
     wi, sh = 0, 0
     qcode = code[query]
-    for kind, val in banded_tokens(length, k):
+    for kind, val in banded_tokens(length, k, phase=0):
         if kind == "event":
             if val & 4:
                 over = st[2] > np.uint32(h + 1)
@@ -848,6 +896,79 @@ def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool 
     return np.where(dead, 127, best).astype(np.int8)
 
 
+def _popcount32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64)
+    return sum(((x >> np.uint64(i)) & np.uint64(1)) for i in range(32)).astype(np.uint32)
+
+
+def _banded_simulate_phase(subjects: np.ndarray, query: np.ndarray, k: int, phase: int) -> np.ndarray:
+    """banded_asm_kernel<false, true> on the CPU: banded_phase_body, the token stream with re-anchor events, the
+    kernel's prologue (window = first match word, mask at offset 0) and epilogue (shift by the rows of the last
+    phase, fold the collected error bits)."""
+    n, length = subjects.shape
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, c in zip(b"ACGTN", range(5)):
+        code[ch] = c
+    mapped = code[subjects]
+    nwords = (length + 31) // 32 + 2
+    mext = np.zeros((5, nwords, n), dtype=np.uint32)
+    for p in range(length):
+        i = p + k + 1
+        for c in range(5):
+            mext[c, i // 32] |= (mapped[:, p] == c).astype(np.uint32) << np.uint32(i % 32)
+    h = k
+    band_mask = np.uint32((1 << (2 * k + 1)) - 1)
+    body = banded_phase_body()
+    z = lambda: np.zeros(n, dtype=np.uint32)
+    st = [z(), z(), z(), np.full(n, band_mask, np.uint32), np.ones(n, np.uint32), z()]
+    W = [mext[c, 0].copy() for c in range(5)]
+    dead = np.zeros(n, dtype=bool)
+    wi, sh, in_phase = 0, 0, 0
+    qcode = code[query]
+    stopped = False
+    for kind, val in banded_tokens(length, k, phase=phase):
+        if kind == "event":
+            if val & 4:
+                over = (st[2] + _popcount32(st[5])) > np.uint32(h + 1)
+                if val & 8:
+                    dead = over.copy()
+                if over.all():
+                    dead[:] = True
+                    stopped = True
+                    break
+            if val & 1:
+                st[2], st[5] = z(), z()
+            if val & 2:
+                wi, sh = wi + 1, 0
+            if val & 16:
+                assert in_phase == phase
+                st[0] = st[0] >> np.uint32(phase)
+                st[1] = st[1] >> np.uint32(phase)
+                st[2] = st[2] + _popcount32(st[5])
+                st[3], st[4], st[5] = np.full(n, band_mask, np.uint32), np.ones(n, np.uint32), z()
+                for c in range(5):
+                    pair = (mext[c, wi + 1].astype(np.uint64) << np.uint64(32)) | mext[c, wi].astype(np.uint64)
+                    W[c] = ((pair >> np.uint64(sh)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                in_phase = 0
+        else:
+            c = int(qcode[val])
+            body.simulate(st, [W[c]])
+            sh += 1
+            in_phase += 1
+    if stopped:
+        return np.full(n, 127, dtype=np.int8)
+    final_shift = length - phase * ((length - 1) // phase)
+    assert final_shift == in_phase
+    vp = st[0] >> np.uint32(final_shift)
+    vn = st[1] >> np.uint32(final_shift)
+    err = (st[2] + _popcount32(st[5])).astype(np.int64) + k
+    best = err.copy()
+    for i in range(h + 1):
+        err = err + ((vp >> np.uint32(i)) & 1) - ((vn >> np.uint32(i)) & 1)
+        best = np.minimum(best, err)
+    return np.where(dead, 127, best).astype(np.int8)
+
+
 def _banded_simulate64(subjects: np.ndarray, query: np.ndarray, k: int) -> np.ndarray:
     n, length = subjects.shape
     code = np.zeros(256, dtype=np.uint8)
@@ -867,7 +988,7 @@ def _banded_simulate64(subjects: np.ndarray, query: np.ndarray, k: int) -> np.nd
     dead = np.zeros(n, dtype=bool)
     wi, sh = 0, 0
     qcode = code[query]
-    for kind, val in banded_tokens(length, k):
+    for kind, val in banded_tokens(length, k, phase=0):
         if kind == "event":
             if val & 4:
                 over = st[4] > np.uint32(h + 1)

@@ -831,7 +831,7 @@ for slen in (150, 310, 700, 1100, 2300):
 qb = O.gen_reads(904, 3, 150); sb = O.gen_reads(905, 130, 150); sb[:10] = O.mutate(qb[np.arange(10) % 3], np.arange(10), 906)
 for k in (8, 31):
     assert np.array_equal(B.align_all_pairs(qb, sb, algo=B.ALGO_BANDED, k=k), O.banded64(qb, sb, k)), ("banded", k)
-for length, k in ((64, 8), (97, 12), (128, 4), (160, 15), (500, 8), (33, 3)):   # chunk boundaries, tails, every special-row position class
+for length, k in ((64, 8), (97, 12), (128, 4), (160, 15), (500, 8), (33, 3), (150, 11), (90, 1), (481, 8), (450, 8)):   # chunk boundaries, tails, every special-row position class
     qc = O.gen_reads(910 + length, 40, length); sc = O.gen_reads(911 + length, 64 * 6, length)
     sc[:64] = O.mutate(qc[np.arange(64) % 40], np.arange(64) % (2 * k + 6), 912)
     sc[64 * 3 + 5] = O.mutate(qc[7:8], [2], 913)[0]; sc[64 * 4 + 60] = O.mutate(qc[9:10], [k], 914)[0]   # lone survivors: regroup pass
@@ -845,6 +845,7 @@ print("knobs ok")
 
 @pytest.mark.parametrize("env", [{"BGSA_MYERS_IMPL": "c", "BGSA_BITPAL_IMPL": "c", "BGSA_BANDED_IMPL": "c"},
                                  {"BGSA_BANDED_IMPL": "s"},                                   # straight-line banded rows (LDS-selected words)
+                                 {"BGSA_BANDED_IMPL": "p"},                                   # the band held in place for k <= 11 (re-anchor events)
                                  {"BGSA_BANDED_PUSH_MAX": "0"},                               # no survivor queue
                                  {"BGSA_BANDED_PUSH_MAX": "64", "BGSA_BANDED_PUSH_ROW": "0"},   # everything alive at the first test is queued
                                  {"BGSA_MYERS_MAX_PLAIN_WORDS": "8"},

@@ -179,6 +179,25 @@ def test_banded_body_and_events_match_oracle(oracle, length, k):
         assert np.array_equal(R.banded_simulate(s, q[i], k), want[i])
 
 
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (64, 8), (65, 8), (200, 8), (150, 11), (33, 1), (100, 10), (31, 3), (481, 8)])
+def test_banded_band_held_in_place_matches_oracle(oracle, length, k):
+    """The alternative form of the 32-bit band (BGSA_BANDED_IMPL=p): classical left shifts inside a phase of
+    banded_phase_rows(k) rows, re-anchor events between phases — same results as the sliding form and the oracle."""
+    phase = R.banded_phase_rows(k)
+    assert phase == 31 - 2 * k
+    q = oracle.gen_reads(3500 + length + k, 3, length)
+    s = oracle.gen_reads(3600 + length + k, 96, length)
+    s[:48] = oracle.mutate(q[np.arange(48) % 3], np.arange(48) % (2 * k + 6), length + k)
+    want = oracle.banded64(q, s, k)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.banded_simulate(s, q[i], k, phase=phase), want[i])
+    assert R.banded_phase_rows(12) == 0 and R.banded_phase_body().valu_count() == 13
+    assert not any(op.kind in ("lshr1", "alignbit") for op in R.banded_phase_body().ops)
+    # the stream: the sliding form's tokens plus one re-anchor event in front of every phase but the first
+    ev = [v for kind, v in R.banded_tokens(length, k, phase=phase) if kind == "event" and v & 16]
+    assert len(ev) == (length - 1) // phase
+
+
 def test_emitted_asm_respects_the_vcc_hazard():
     for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5), R.myers_planes_body(12), R.myers_block_body(12)):
         lines = body.emit_asm(lambda name: name)
