@@ -6,6 +6,7 @@ thresholds / score sets / alignment modes, every result compared with the oracle
 
 Prints a progress line every ~20 s (the GPU box kills silent jobs) and a summary; exit code 1 on the
 first mismatch, with the failing case spelled out so that it can be turned into a test."""
+import os
 import sys
 import time
 from pathlib import Path
@@ -42,6 +43,10 @@ def main() -> int:
             k = 0
             hi = 4200 if long_case else 420
             qlen, slen = int(rng.integers(1, hi)), int(rng.integers(1, hi))
+            if os.environ.get("SOAK_SLEN_RANGE"):     # focus on one kernel family, e.g. 769,1024: the code-plane kernels
+                lo_s, hi_s = (int(x) for x in os.environ["SOAK_SLEN_RANGE"].split(","))
+                slen = int(rng.integers(lo_s, hi_s + 1))
+                qlen = int(rng.integers(1, 1400))
         nq = int(rng.integers(1, 9 if long_case else 40))
         ns = int(rng.integers(1, 200 if long_case else 700))
         q = O.gen_reads(int(rng.integers(1 << 30)), nq, qlen)
