@@ -465,6 +465,7 @@ def main() -> int:
 
     # ---- N > 1: the same steps with the score gather of SURVEY §2a C3 streamed beside them -------------------
     gather_info = None
+    print_lock, printed = threading.Lock(), []     # the one JSON line is printed once, by main() or by the watchdog
     gather_wanted = dist is not None and world > 1 and os.environ.get("BGSA_BENCH_GATHER", "1") != "0"
     watchdog = None
     if gather_wanted:
@@ -473,10 +474,11 @@ def main() -> int:
         limit = float(os.environ.get("BGSA_BENCH_GATHER_TIMEOUT", "180"))
 
         def give_up():
-            if rank == 0:
-                result["gather"] = {"error": f"gather leg did not finish within {limit:.0f} s; value is the kernel-only figure"}
-                print(json.dumps(result), flush=True)
-            os._exit(0)
+            with print_lock:
+                if rank == 0 and not printed:
+                    result["gather"] = {"error": f"gather leg did not finish within {limit:.0f} s; value is the kernel-only figure"}
+                    print(json.dumps(result), flush=True)
+                os._exit(0)      # also ends a rank that printed its line and then hung in the closing barrier
 
         watchdog = threading.Timer(limit, give_up)
         watchdog.daemon = True
@@ -568,7 +570,9 @@ def main() -> int:
             result["cpu_baseline"] = cpu_baseline(q_rows[:cq].cpu().numpy(), s_rows[:cs, :length].cpu().numpy(), algo, k)
             result["cpu_baseline"]["gpu_over_cpu"] = round(gcups / result["cpu_baseline"]["value"], 1)
             result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 2)
-        print(json.dumps(result), flush=True)
+        with print_lock:
+            print(json.dumps(result), flush=True)
+            printed.append(True)
     if dist is not None:
         dist.barrier()
         if watchdog is not None:
