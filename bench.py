@@ -474,6 +474,8 @@ def main() -> int:
         limit = float(os.environ.get("BGSA_BENCH_GATHER_TIMEOUT", "180"))
 
         def give_up():
+            if rank != 0:
+                time.sleep(2.0)     # let rank 0 get its line out before peers start to disappear under it
             with print_lock:
                 if rank == 0 and not printed:
                     result["gather"] = {"error": f"gather leg did not finish within {limit:.0f} s; value is the kernel-only figure"}
@@ -491,10 +493,13 @@ def main() -> int:
             gs = ScoreGatherStream(dist, dev, [s.count for s in all_shards], aligner.out_dtype, block_rows=REF_BUCKET_COUNT)
         except Exception as e:
             setup_error = repr(e)
-        ok = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            gather_info = {"error": setup_error or "set-up failed on another rank"}
+        try:
+            ok = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                gather_info = {"error": setup_error or "set-up failed on another rank"}
+        except Exception as e:   # a peer that is gone (e.g. its watchdog fired first) must not take the line with it
+            gather_info = {"error": repr(e)}
     if gather_info is None and gather_wanted:
         try:
             nq_g = min(nq, 10 * REF_BUCKET_COUNT)     # ten reference-sized blocks are enough to see the steady state
@@ -574,10 +579,16 @@ def main() -> int:
             print(json.dumps(result), flush=True)
             printed.append(True)
     if dist is not None:
-        dist.barrier()
+        try:
+            dist.barrier()
+        except Exception as e:       # the line is out; a peer that left early is not this rank's failure
+            print(f"[bench] closing barrier: {e!r}", file=sys.stderr)
         if watchdog is not None:
             watchdog.cancel()
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
     return 0
 
 
