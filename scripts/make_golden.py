@@ -8,7 +8,7 @@ Run in the build container only (needs /root/reference to have been compiled by
     python scripts/make_golden.py            # regenerate every fixture
     python scripts/make_golden.py --check    # regenerate in memory and compare with the files
 
-Fixture list follows SURVEY.md §8(c) "Fixtures to mint" (F1..F9).
+Fixture list follows SURVEY.md §8(c) "Fixtures to mint" (F1..F9), plus F0: the reference's own sample data.
 """
 from __future__ import annotations
 
@@ -47,8 +47,26 @@ def with_specials(rows: np.ndarray, seed: int) -> np.ndarray:
     return rows
 
 
+SAMPLE_DATA = Path("/root/reference/original/BGSA_CPU/sample-data")   # the reference's only smoke data
+
+
+def read_lines(path: Path) -> np.ndarray:
+    rows = [ln for ln in path.read_bytes().split(b"\n") if ln]
+    assert len({len(r) for r in rows}) == 1
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), -1).copy()
+
+
 def fixtures():
     """Yield (name, variant, k, queries, subjects)."""
+    # F0: the reference's own sample data (3 x 500 bp queries, 128 x 500 bp subjects: the `./aligner -q sample-data/
+    # query.txt -d sample-data/subject.txt` run of its README), scored by each compiled variant.  Data files, read
+    # here in the build container only; when /root/reference is absent the committed fixtures are simply kept.
+    if SAMPLE_DATA.exists():
+        q, s = read_lines(SAMPLE_DATA / "query.txt"), read_lines(SAMPLE_DATA / "subject.txt")
+        yield "f0_sample_myers", "original_cpu", None, q, s
+        yield "f0_sample_bitpal", "original_avx2", None, q, s
+        yield "f0_sample_banded_k8", "banded_cpu", 8, q, s
+        yield "f0_sample_banded_k31", "banded_cpu", 31, q, s
     # F1 + F3: Myers 150 bp, random + planted near-duplicates (0..30 edits)
     q = O.gen_reads(0xB65A0001, 64, 150)
     s = planted(q, 256, 30, 11, 0xB65A1001)
