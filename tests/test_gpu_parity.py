@@ -425,6 +425,63 @@ def test_host_surface_bitpal(oracle, fixture):
         L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
 
 
+@pytest.mark.parametrize("algo,nq,k", [(B.ALGO_MYERS, 70, 0), (B.ALGO_BANDED, 133, 8), (B.ALGO_BITPAL, 67, 0)])
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_seam_copy_out_in_tiles(oracle, algo, nq, k, pinned):
+    """A block large enough (>= 8 MiB of scores) for hip_cal_align_score to score it in query tiles and copy tile t
+    out while tile t+1 runs: the caller's buffer must hold every score on return — whole matrix against the
+    device-resident path (same kernels), a slice of it against the oracle; with page-locked and pageable buffers,
+    uneven tiles (nq not a multiple of 8) and a ref_start / ref_end window."""
+    import torch
+    L = B.lib()
+    n, length = 64 * 1024, 150
+    q = oracle.gen_reads(1300 + algo, nq, length)
+    s = oracle.gen_reads(1400 + algo, n, length)
+    s[:256] = oracle.mutate(q[np.arange(256) % nq], np.arange(256) % 12, 1500 + algo)
+    esz = 1 if algo == B.ALGO_BANDED else 2
+    dtype = np.int8 if esz == 1 else np.int16
+    a = B.DeviceAligner(algo, k=k)
+    a.set_queries(q)
+    a.set_subjects(s)
+    want = a.score().cpu().numpy()[:, :n]
+    fn = {B.ALGO_MYERS: oracle.myers64, B.ALGO_BITPAL: oracle.bitpal, B.ALGO_BANDED: lambda x, y: oracle.banded64(x, y, k)}[algo]
+    assert np.array_equal(want[:, :320], fn(q, s[:320]))
+    threshold = ctypes.c_int.in_dll(L, "threshold")
+    old_threshold = threshold.value
+    L.bgsa_hip_select_algorithm(algo)
+    bufs = []
+    try:
+        threshold.value = k if algo == B.ALGO_BANDED else old_threshold
+        L.init_mapping_table()
+        sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+        wn = B.word_num(algo, length, length, k)
+        n_peq = B.group_words(algo, wn, k) * (n // 64)
+        if pinned:
+            p1, p2 = L.malloc_mem(n_peq * 4), L.malloc_mem(nq * n * esz)
+            bufs = [p1, p2]
+            peq = np.ctypeslib.as_array(ctypes.cast(p1, ctypes.POINTER(ctypes.c_uint32)), shape=(n_peq,))
+            out = np.ctypeslib.as_array(ctypes.cast(p2, ctypes.POINTER(ctypes.c_int8 if esz == 1 else ctypes.c_int16)), shape=(nq, n))
+        else:
+            peq, out = np.zeros(n_peq, dtype=np.uint32), np.zeros((nq, n), dtype=dtype)
+        peq[:] = 0
+        L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+        out[:] = 99
+        L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, length, nq, length, n, 0, nq, wn, 27, None)
+        assert np.array_equal(out, want)
+        # a window of the queries: rows relative to ref_start, the rest of the buffer untouched
+        out[:] = 99
+        lo, hi = 3, nq - 2
+        L.hip_cal_align_score(qmapped.ctypes.data, peq.ctypes.data, out.ctypes.data, length, nq, length, n, lo, hi, wn, 27, None)
+        assert np.array_equal(out[: hi - lo], want[lo:hi]) and bool((out[hi - lo:] == 99).all())
+        torch.cuda.synchronize()
+        assert L.bgsa_hip_stream_faults(1) == 0
+    finally:
+        for p in bufs:
+            L.free_mem(p)
+        threshold.value = old_threshold
+        L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+
+
 def test_host_seam_keeps_the_bucket_resident(oracle):
     """100-query blocks against one bucket: the Peq words cross PCIe once, not once per call; rewriting
     the buffer with hip_handle_reads invalidates the device copy; auto-residency can be switched off."""
