@@ -254,6 +254,7 @@ void init_mapping_table(void)
 // Small blocks, and everything when no GPU is visible, come from the C heap.
 static std::mutex g_pinned_mu;
 static std::map<void *, size_t> g_pinned;
+static std::map<void *, size_t> g_heap_blocks;   // the small blocks: only their extent is of interest (align_hip's read-ahead)
 static const size_t kPinThreshold = 1u << 20;
 static void forget_host_range(const void *p, size_t bytes);   // a freed buffer cannot stay a resident bucket
 
@@ -272,8 +273,26 @@ void *malloc_mem(uint64_t size)
     }
     void *p = nullptr;
     if (posix_memalign(&p, 64, size ? size : 64) != 0) return nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mu);
+        g_heap_blocks[p] = size;
+    }
     return p;
 }
+// Bytes from p to the end of the malloc_mem() block that holds it (0: p is not inside a block of ours).
+static size_t block_bytes_after(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    for (const std::map<void *, size_t> *m : {&g_pinned, &g_heap_blocks}) {
+        auto it = m->upper_bound(const_cast<void *>(p));
+        if (it == m->begin()) continue;
+        --it;
+        const unsigned char *base = static_cast<const unsigned char *>(it->first), *q = static_cast<const unsigned char *>(p);
+        if (q < base + it->second) return static_cast<size_t>(base + it->second - q);
+    }
+    return 0;
+}
+
 void free_mem(void *mem)
 {
     if (!mem) return;
@@ -285,6 +304,7 @@ void free_mem(void *mem)
             pinned_bytes = it->second;
             g_pinned.erase(it);
         }
+        g_heap_blocks.erase(mem);
     }
     forget_host_range(mem, pinned_bytes ? pinned_bytes : 1);
     if (pinned_bytes)
@@ -757,12 +777,74 @@ static int upload_peq(void *dev, const void *host, size_t groups, int w_host, in
 // taken literally.  With the bucket resident, the first call for a query scores it against the WHOLE bucket in
 // one launch and keeps the row on the host; the other 578 calls for that query are a memcpy of their chunk.
 // A row is identified by the bucket's content id, the query's bytes and the scoring parameters.
+// Where a cached row lives: a slot of one page-locked arena (the device-to-host copy lands in it directly — staging
+// a row and copying it once more cost more than scoring it), or, when the arena has no slot of that size, the heap.
+struct RowBuf {
+    unsigned char *p = nullptr;
+    size_t size = 0;
+    int slot = -1;            // >= 0: arena slot, given back when the last holder lets go; -1: heap
+};
+struct RowArena {
+    std::mutex mu;            // the free list: rows are released by whichever thread drops the last reference
+    unsigned char *base = nullptr;
+    size_t slot_bytes = 0;
+    std::vector<int> free_slots;
+    bool tried = false;
+};
+static RowArena g_arena;
+static constexpr size_t kRowArenaBytes = size_t(1) << 30;
+
+static void row_release(RowBuf *b)
+{
+    if (b->slot >= 0) {
+        std::lock_guard<std::mutex> lock(g_arena.mu);
+        g_arena.free_slots.push_back(b->slot);
+    } else {
+        delete[] b->p;
+    }
+    delete b;
+}
+
+// A buffer for one row of `size` bytes; *pinned says whether a device copy may land in it directly.
+static std::shared_ptr<RowBuf> row_take(size_t size, bool *pinned)   // g_seam held
+{
+    RowBuf *b = new RowBuf;
+    b->size = size;
+    {
+        std::lock_guard<std::mutex> lock(g_arena.mu);
+        if (!g_arena.tried) {      // carved once, for the row size of the first bucket seen
+            g_arena.tried = true;
+            const size_t slot = (size + 4095) & ~size_t(4095);
+            size_t bytes = kRowArenaBytes;
+            while (bytes >= 4 * slot && bytes >= (size_t(64) << 20)) {
+                void *m = nullptr;
+                if (hipHostMalloc(&m, bytes, hipHostMallocPortable) == hipSuccess && m) {
+                    g_arena.base = static_cast<unsigned char *>(m);
+                    g_arena.slot_bytes = slot;
+                    for (int i = static_cast<int>(bytes / slot) - 1; i >= 0; i--) g_arena.free_slots.push_back(i);
+                    break;
+                }
+                (void)hipGetLastError();
+                bytes >>= 1;
+            }
+        }
+        if (g_arena.base && size <= g_arena.slot_bytes && !g_arena.free_slots.empty()) {
+            b->slot = g_arena.free_slots.back();
+            g_arena.free_slots.pop_back();
+            b->p = g_arena.base + static_cast<size_t>(b->slot) * g_arena.slot_bytes;
+        }
+    }
+    if (b->slot < 0) b->p = new unsigned char[size ? size : 1];
+    *pinned = b->slot >= 0;
+    return std::shared_ptr<RowBuf>(b, row_release);
+}
+
 struct CachedRow {
     uint64_t range_gen = 0;
     bgsa_hip_params_t params{};
     int read_len = 0;
     std::string query;                                         // the mapped query row, ref_len bytes
-    std::shared_ptr<std::vector<unsigned char>> scores;        // [subjects of the range] x element size
+    std::shared_ptr<RowBuf> scores;                            // [subjects of the range] x element size
     uint64_t stamp = 0;
 };
 
@@ -777,7 +859,9 @@ struct HostSeam {
     std::vector<CachedRow> rows;
     void *h_stage = nullptr;           // page-locked landing buffer of a row (copies to pageable memory are far slower)
     size_t cap_stage = 0;
-    uint64_t next_gen = 1, clock = 0, row_hits = 0, row_misses = 0;
+    uint64_t next_gen = 1, clock = 0, row_hits = 0, row_misses = 0, rows_ahead = 0;
+    const unsigned char *last_miss = nullptr;   // where align_hip's previous row miss was (read-ahead heuristic)
+    size_t last_miss_stride = 0;
     size_t row_bytes = 0;
     static constexpr size_t kRowCacheBytes = 1u << 30;
     std::vector<unsigned char> content_copy;   // what d_content holds
@@ -810,7 +894,7 @@ static void drop_overlapping(const unsigned char *lo, size_t bytes)  // g_seam h
             if (r.dev) (void)hipFree(r.dev);
             for (size_t j = 0; j < g_host.rows.size();) {      // its cached rows go with it
                 if (g_host.rows[j].range_gen == r.gen) {
-                    g_host.row_bytes -= g_host.rows[j].scores->size();
+                    g_host.row_bytes -= g_host.rows[j].scores->size;
                     g_host.rows.erase(g_host.rows.begin() + j);
                 } else {
                     j++;
@@ -836,6 +920,17 @@ static int seam_tiles()
         const char *e = getenv("BGSA_HIP_SEAM_TILES");
         const int v = e ? atoi(e) : HostSeam::kCopyTiles;
         return (v >= 1 && v <= HostSeam::kCopyTiles) ? v : HostSeam::kCopyTiles;
+    }();
+    return n;
+}
+
+// Query rows align_hip scores per launch when the calls walk a query buffer (BGSA_HIP_ROW_AHEAD, 1..64; 1 = none).
+static int seam_row_ahead()
+{
+    static const int n = [] {
+        const char *e = getenv("BGSA_HIP_ROW_AHEAD");
+        const int v = e ? atoi(e) : 16;     // 10k x 1M through the reference's own pipeline: cal 3.81 / 3.33 / 3.29 / 3.46 s at 1 / 8 / 16 / 32
+        return (v >= 1 && v <= 64) ? v : 16;
     }();
     return n;
 }
@@ -955,10 +1050,10 @@ int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_up
 static std::atomic<uint64_t> g_row_ns{0}, g_lock_wait_ns{0};
 static void print_seam_stats()
 {
-    fprintf(stderr, "[bgsa_hip] seam calls %llu, Peq uploads %llu (%.1f MB), align_hip rows computed %llu in %.3f s, served from a row: "
-                    "%llu under the lock + %llu from the caller's last row; waited for the seam lock %.3f s\n",
+    fprintf(stderr, "[bgsa_hip] seam calls %llu, Peq uploads %llu (%.1f MB), align_hip row launches %llu (+ %llu rows read ahead) in %.3f s, "
+                    "served from a row: %llu under the lock + %llu from the caller's last row; waited for the seam lock %.3f s\n",
             (unsigned long long)g_host.calls, (unsigned long long)g_host.peq_uploads, g_host.peq_upload_bytes / 1e6,
-            (unsigned long long)g_host.row_misses, g_row_ns.load() / 1e9, (unsigned long long)g_host.row_hits,
+            (unsigned long long)g_host.row_misses, (unsigned long long)g_host.rows_ahead, g_row_ns.load() / 1e9, (unsigned long long)g_host.row_hits,
             (unsigned long long)g_row_fast_hits.load(), g_lock_wait_ns.load() / 1e9);
 }
 static void seam_stats_at_exit()
@@ -1143,7 +1238,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
         bgsa_hip_params_t params{};
         int read_len = 0, word_num = 0;
         std::string query;
-        std::shared_ptr<std::vector<unsigned char>> scores;
+        std::shared_ptr<RowBuf> scores;
     };
     static thread_local LastRow last;
     if (chunk_read_num > 0 && ref && read && results && ref_len > 0) {
@@ -1158,7 +1253,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 memcmp(last.query.data(), ref, ref_len) == 0) {
                 const size_t esz = result_elem_size(params.algo);
                 memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
-                       last.scores->data() + (peq_host - last.range_host) / last.group_bytes * HIP_V_NUM * esz,
+                       last.scores->p + (peq_host - last.range_host) / last.group_bytes * HIP_V_NUM * esz,
                        static_cast<size_t>(chunk_read_num) * HIP_V_NUM * esz);
                 g_row_fast_hits.fetch_add(1, std::memory_order_relaxed);
                 return;
@@ -1178,7 +1273,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
             if (r) {
                 g_host.calls++;
                 const size_t r_groups = r->bytes / host_group_bytes, first_group = (peq_host - r->host) / host_group_bytes;
-                std::shared_ptr<std::vector<unsigned char>> row;
+                std::shared_ptr<RowBuf> row;
                 for (CachedRow &c : g_host.rows)
                     if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
                         memcmp(&c.params, &params, sizeof params) == 0 && memcmp(c.query.data(), ref, ref_len) == 0) {
@@ -1191,50 +1286,101 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                     g_host.row_misses++;
                     const uint64_t t_row = now_ns();
                     hipStream_t s = g_host.stream;
-                    const size_t n_sub = r_groups * HIP_V_NUM;
-                    if (g_host.reserve(&g_host.d_rowq, &g_host.cap_rowq, static_cast<size_t>(ref_len) + 16) ||
-                        g_host.reserve(&g_host.d_results, &g_host.cap_results, n_sub * esz))
+                    const size_t n_sub = r_groups * HIP_V_NUM, row_size = n_sub * esz, stride = static_cast<size_t>(ref_len) + 1;
+                    // Read-ahead: the reference's grid walks the query buffer row after row (cal_cpu.c:63-84), so when this
+                    // miss sits near the previous one inside a malloc_mem() block, the rows behind it are scored in the same
+                    // launch.  A row is only ever served for a query with the same bytes, so a wrong guess costs time, never
+                    // results.
+                    int n_rows = 1;
+                    const unsigned char *uref = reinterpret_cast<const unsigned char *>(ref);
+                    const size_t extent = block_bytes_after(ref);
+                    const bool near_last = g_host.last_miss && g_host.last_miss_stride == stride &&
+                                           (uref > g_host.last_miss ? static_cast<size_t>(uref - g_host.last_miss)
+                                                                    : static_cast<size_t>(g_host.last_miss - uref)) <= 64 * stride;
+                    auto cached = [&](const char *qrow_bytes) {   // a row another launch has scored already ends the run
+                        for (const CachedRow &c : g_host.rows)
+                            if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
+                                memcmp(c.query.data(), qrow_bytes, ref_len) == 0 && memcmp(&c.params, &params, sizeof params) == 0)
+                                return true;
+                        return false;
+                    };
+                    if (near_last && extent >= stride && uref[ref_len] == '\n')
+                        while (n_rows < seam_row_ahead() && static_cast<size_t>(n_rows + 1) * stride <= extent &&
+                               uref[static_cast<size_t>(n_rows) * stride + ref_len] == '\n' &&
+                               !cached(ref + static_cast<size_t>(n_rows) * stride))
+                            n_rows++;
+                    g_host.last_miss = uref;
+                    g_host.last_miss_stride = stride;
+                    if (g_host.reserve(&g_host.d_rowq, &g_host.cap_rowq, static_cast<size_t>(n_rows) * stride + 16) ||
+                        g_host.reserve(&g_host.d_results, &g_host.cap_results, static_cast<size_t>(n_rows) * row_size))
                         die("align_hip");
-                    std::string qrow(ref, ref + ref_len);
-                    qrow.push_back('\n');
-                    if (g_host.cap_stage < n_sub * esz) {
-                        if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
-                        g_host.h_stage = nullptr;
-                        g_host.cap_stage = 0;
-                        if (hipHostMalloc(&g_host.h_stage, n_sub * esz, hipHostMallocPortable) != hipSuccess) {
-                            set_error_text("align_hip: hipHostMalloc (row staging) failed");
-                            die("align_hip");
-                        }
-                        g_host.cap_stage = n_sub * esz;
+                    std::string qrow;
+                    const void *q_src = ref;
+                    if (n_rows == 1) {   // a lone row may not be followed by its terminator in the caller's memory
+                        qrow.assign(ref, ref + ref_len);
+                        qrow.push_back('\n');
+                        q_src = qrow.data();
                     }
-                    if (hipMemcpyAsync(g_host.d_rowq, qrow.data(), qrow.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
-                        bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_rowq),
-                                                    static_cast<const hip_read_t *>(r->dev), g_host.d_results, ref_len, read_len,
-                                                    static_cast<int64_t>(n_sub), 0, 1, w_dev, nullptr, 0, s) != BGSA_HIP_OK ||
-                        hipMemcpyAsync(g_host.h_stage, g_host.d_results, n_sub * esz, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                        hipStreamSynchronize(s) != hipSuccess) {
-                        if (g_last_error.empty()) set_error_text("align_hip: scoring the query row failed");
-                        die("align_hip");
-                    }
-                    const unsigned char *staged = static_cast<const unsigned char *>(g_host.h_stage);
-                    row = std::make_shared<std::vector<unsigned char>>(staged, staged + n_sub * esz);
-                    if (bgsa_hip_stream_faults(1) != 0) die("align_hip");
-                    while (!g_host.rows.empty() && g_host.row_bytes + row->size() > HostSeam::kRowCacheBytes) {
+                    // room for the new rows: the least recently used ones go first
+                    while (!g_host.rows.empty() && g_host.row_bytes + static_cast<size_t>(n_rows) * row_size > HostSeam::kRowCacheBytes) {
                         size_t oldest = 0;
                         for (size_t j = 1; j < g_host.rows.size(); j++)
                             if (g_host.rows[j].stamp < g_host.rows[oldest].stamp) oldest = j;
-                        g_host.row_bytes -= g_host.rows[oldest].scores->size();
+                        g_host.row_bytes -= g_host.rows[oldest].scores->size;
                         g_host.rows.erase(g_host.rows.begin() + oldest);
                     }
-                    CachedRow c;
-                    c.range_gen = r->gen;
-                    c.params = params;
-                    c.read_len = read_len;
-                    c.query.assign(ref, ref + ref_len);
-                    c.scores = row;
-                    c.stamp = ++g_host.clock;
-                    g_host.row_bytes += row->size();
-                    g_host.rows.push_back(std::move(c));
+                    std::vector<std::shared_ptr<RowBuf>> bufs(n_rows);
+                    std::vector<bool> direct(n_rows);
+                    bool any_staged = false;
+                    for (int j = 0; j < n_rows; j++) {
+                        bool pinned = false;
+                        bufs[j] = row_take(row_size, &pinned);
+                        direct[j] = pinned;
+                        any_staged = any_staged || !pinned;
+                    }
+                    if (any_staged && g_host.cap_stage < row_size) {
+                        if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
+                        g_host.h_stage = nullptr;
+                        g_host.cap_stage = 0;
+                        if (hipHostMalloc(&g_host.h_stage, row_size, hipHostMallocPortable) != hipSuccess) {
+                            set_error_text("align_hip: hipHostMalloc (row staging) failed");
+                            die("align_hip");
+                        }
+                        g_host.cap_stage = row_size;
+                    }
+                    bool ok = hipMemcpyAsync(g_host.d_rowq, q_src, static_cast<size_t>(n_rows) * stride, hipMemcpyHostToDevice, s) == hipSuccess &&
+                              bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_rowq),
+                                                          static_cast<const hip_read_t *>(r->dev), g_host.d_results, ref_len, read_len,
+                                                          static_cast<int64_t>(n_sub), 0, n_rows, w_dev, nullptr, 0, s) == BGSA_HIP_OK;
+                    for (int j = 0; ok && j < n_rows; j++)
+                        if (direct[j])
+                            ok = hipMemcpyAsync(bufs[j]->p, static_cast<unsigned char *>(g_host.d_results) + static_cast<size_t>(j) * row_size,
+                                                row_size, hipMemcpyDeviceToHost, s) == hipSuccess;
+                    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+                    for (int j = 0; ok && j < n_rows; j++)
+                        if (!direct[j]) {   // no arena slot: through the staging buffer, one row at a time
+                            ok = hipMemcpyAsync(g_host.h_stage, static_cast<unsigned char *>(g_host.d_results) + static_cast<size_t>(j) * row_size,
+                                                row_size, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                            if (ok) memcpy(bufs[j]->p, g_host.h_stage, row_size);
+                        }
+                    if (!ok) {
+                        if (g_last_error.empty()) set_error_text("align_hip: scoring the query rows failed");
+                        die("align_hip");
+                    }
+                    if (bgsa_hip_stream_faults(1) != 0) die("align_hip");
+                    for (int j = 0; j < n_rows; j++) {
+                        CachedRow c;
+                        c.range_gen = r->gen;
+                        c.params = params;
+                        c.read_len = read_len;
+                        c.query.assign(ref + static_cast<size_t>(j) * stride, ref + static_cast<size_t>(j) * stride + ref_len);
+                        c.scores = bufs[j];
+                        c.stamp = ++g_host.clock;
+                        g_host.row_bytes += row_size;
+                        g_host.rows.push_back(std::move(c));
+                    }
+                    g_host.rows_ahead += static_cast<uint64_t>(n_rows - 1);
+                    row = bufs[0];
                     g_row_ns.fetch_add(now_ns() - t_row, std::memory_order_relaxed);
                 }
                 last.epoch = g_range_epoch.load(std::memory_order_acquire);
@@ -1248,7 +1394,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 last.scores = row;
                 turn.unlock();   // the copy needs no lock: the row is shared, immutable
                 memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
-                       row->data() + first_group * HIP_V_NUM * esz, static_cast<size_t>(chunk_read_num) * HIP_V_NUM * esz);
+                       row->p + first_group * HIP_V_NUM * esz, static_cast<size_t>(chunk_read_num) * HIP_V_NUM * esz);
                 return;
             }
         }

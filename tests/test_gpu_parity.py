@@ -593,6 +593,57 @@ def test_align_hip_grid_uses_the_row_cache(oracle):
     L.bgsa_hip_bucket_release(None)
 
 
+def test_align_hip_reads_ahead_in_a_query_buffer(oracle):
+    """align_hip walking a malloc_mem() query buffer row after row, as the reference's grid does: from the second miss
+    on, the rows behind the requested one are scored in the same launch and land in the page-locked row arena; a row is
+    only served for the same query bytes, so a query edited in place afterwards is scored again."""
+    L = B.lib()
+    nq, length = 40, 150
+    q = oracle.gen_reads(81, nq, length)
+    s, _ = B.pad_rows(oracle.gen_reads(82, 64 * 5, length))
+    s[:nq] = oracle.mutate(q, np.arange(nq) % 9, 83)
+    want = oracle.myers64(q, s)
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.init_mapping_table()
+    sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+    wn, n = 5, s.shape[0]
+    gw = B.group_words(B.ALGO_MYERS, wn)
+    peq = np.zeros(gw * (n // 64), dtype=np.uint32)
+    L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+    block = L.malloc_mem(2 << 20)                      # page-locked, its extent known to the library
+    try:
+        qbuf = np.ctypeslib.as_array(ctypes.cast(block, ctypes.POINTER(ctypes.c_uint8)), shape=(2 << 20,))
+        qbuf[:] = 0
+        qbuf[: nq * (length + 1)] = qmapped[: nq * (length + 1)]
+
+        def misses():
+            h, m = ctypes.c_uint64(), ctypes.c_uint64()
+            L.bgsa_hip_row_cache_stats(ctypes.byref(h), ctypes.byref(m))
+            return m.value
+
+        m0 = misses()
+        out = np.zeros((nq, n), dtype=np.int16)
+        for i in range(nq):
+            L.align_hip(block + i * (length + 1), peq.ctypes.data, length, length, wn, n // 64, i * (n // 64), out.ctypes.data, None)
+        assert np.array_equal(out, want)
+        assert misses() - m0 == 4                      # query 0 alone, then 1..16, 17..32 and 33..39 with their followers
+        # the query bytes decide, not the address: an edited row is scored again, its neighbours still come from their rows
+        q2 = q.copy()
+        q2[5] = oracle.gen_reads(84, 1, length)[0]
+        _, _, qm2 = _host_seam_inputs(L, q2, s)
+        qbuf[5 * (length + 1): 6 * (length + 1)] = qm2[5 * (length + 1): 6 * (length + 1)]
+        res = np.zeros(n, dtype=np.int16)
+        m1 = misses()
+        L.align_hip(block + 5 * (length + 1), peq.ctypes.data, length, length, wn, n // 64, 0, res.ctypes.data, None)
+        assert np.array_equal(res, oracle.myers64(q2[5:6], s)[0]) and misses() > m1
+        m2 = misses()
+        L.align_hip(block + 6 * (length + 1), peq.ctypes.data, length, length, wn, n // 64, 0, res.ctypes.data, None)
+        assert np.array_equal(res, want[6]) and misses() == m2
+    finally:
+        L.bgsa_hip_bucket_release(None)
+        L.free_mem(block)
+
+
 def test_wrong_word_num_is_refused(oracle):
     # the kernels index the blocks with the caller's word_num: anything but the layout's own value is an error
     import torch
