@@ -787,7 +787,7 @@ struct RowBuf {
 struct RowArena {
     std::mutex mu;            // the free list: rows are released by whichever thread drops the last reference
     unsigned char *base = nullptr;
-    size_t slot_bytes = 0;
+    size_t slot_bytes = 0, n_slots = 0;
     std::vector<int> free_slots;
     bool tried = false;
 };
@@ -815,12 +815,13 @@ static std::shared_ptr<RowBuf> row_take(size_t size, bool *pinned)   // g_seam h
         if (!g_arena.tried) {      // carved once, for the row size of the first bucket seen
             g_arena.tried = true;
             const size_t slot = (size + 4095) & ~size_t(4095);
-            size_t bytes = kRowArenaBytes;
+            size_t bytes = std::min(kRowArenaBytes, std::max(size_t(64) << 20, 512 * slot));   // small buckets: a small arena
             while (bytes >= 4 * slot && bytes >= (size_t(64) << 20)) {
                 void *m = nullptr;
                 if (hipHostMalloc(&m, bytes, hipHostMallocPortable) == hipSuccess && m) {
                     g_arena.base = static_cast<unsigned char *>(m);
                     g_arena.slot_bytes = slot;
+                    g_arena.n_slots = bytes / slot;
                     for (int i = static_cast<int>(bytes / slot) - 1; i >= 0; i--) g_arena.free_slots.push_back(i);
                     break;
                 }
@@ -837,6 +838,26 @@ static std::shared_ptr<RowBuf> row_take(size_t size, bool *pinned)   // g_seam h
     if (b->slot < 0) b->p = new unsigned char[size ? size : 1];
     *pinned = b->slot >= 0;
     return std::shared_ptr<RowBuf>(b, row_release);
+}
+
+// Rows of `size` bytes do not fit the arena's slots (it was carved for a smaller bucket): true if the arena is idle —
+// the caller has dropped its cached rows and no thread holds one — and has been given up, so that the next row_take()
+// carves it anew for this size.
+static bool row_arena_recarve(size_t size)   // g_seam held
+{
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    if (!g_arena.base || size <= g_arena.slot_bytes || g_arena.free_slots.size() != g_arena.n_slots) return false;
+    (void)hipHostFree(g_arena.base);
+    g_arena.base = nullptr;
+    g_arena.slot_bytes = g_arena.n_slots = 0;
+    g_arena.free_slots.clear();
+    g_arena.tried = false;
+    return true;
+}
+static bool row_arena_too_small(size_t size)
+{
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    return g_arena.base && size > g_arena.slot_bytes;
 }
 
 struct CachedRow {
@@ -1328,6 +1349,12 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                             if (g_host.rows[j].stamp < g_host.rows[oldest].stamp) oldest = j;
                         g_host.row_bytes -= g_host.rows[oldest].scores->size;
                         g_host.rows.erase(g_host.rows.begin() + oldest);
+                    }
+                    if (row_arena_too_small(row_size)) {   // a bigger bucket than the arena was carved for: start it over
+                        g_host.rows.clear();
+                        g_host.row_bytes = 0;
+                        last.scores.reset();
+                        (void)row_arena_recarve(row_size);
                     }
                     std::vector<std::shared_ptr<RowBuf>> bufs(n_rows);
                     std::vector<bool> direct(n_rows);
