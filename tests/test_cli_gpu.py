@@ -283,3 +283,18 @@ def test_banded_reference_host_default_threshold(tmp_path, oracle):
     got, _ = _run_banded_host(tmp_path, {"queries": q, "subjects": s}, None)
     want = oracle.banded64(q, s, 31)
     assert np.array_equal(got, want) and (want != 127).any() and (want == 127).any()
+
+
+def test_readme_demo_on_the_hip_backend(oracle):
+    """The reference README's "use the kernel alignment method" demo (README.md:94-165: AAAA against AAAA, AACA, CAAC,
+    AGGG) written against this library (examples/demo/demo_hip.c): built with plain gcc, run on the GPU."""
+    demo = ROOT / "examples" / "demo"
+    subprocess.run(["make", "-C", str(demo)], check=True, capture_output=True)
+    q = np.frombuffer(b"AAAA", dtype=np.uint8).reshape(1, 4)
+    s = np.frombuffer(b"AAAAAACACAACAGGG", dtype=np.uint8).reshape(4, 4)
+    p = subprocess.run([str(demo / "demo_hip")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert [int(x) for x in p.stdout.split()] == [0, -1, -2, -3] == oracle.myers64(q, s)[0].tolist()
+    p = subprocess.run([str(demo / "demo_hip"), "bitpal"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert [int(x) for x in p.stdout.split()] == oracle.bitpal(q, s)[0].tolist() == oracle.dp_nw(q, s, 2, -3, -5)[0].tolist()
