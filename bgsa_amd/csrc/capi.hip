@@ -779,10 +779,26 @@ static int upload_peq(void *dev, const void *host, size_t groups, int w_host, in
 // A row is identified by the bucket's content id, the query's bytes and the scoring parameters.
 // Where a cached row lives: a slot of one page-locked arena (the device-to-host copy lands in it directly — staging
 // a row and copying it once more cost more than scoring it), or, when the arena has no slot of that size, the heap.
+// One launch of align_hip's row cache: its rows are in the cache as soon as the launch is issued, usable once `done`
+// (recorded behind the last copy down) has been waited for.  A batch issued ahead of the calls runs on the GPU while
+// the host threads are still copying chunks out of the previous one.
+struct RowBuf;
+struct RowBatch {
+    hipEvent_t done = nullptr;
+    bool waited = false;
+    bool chained = false;                 // the batch behind this one has been issued (or cannot be)
+    bool full = false;                    // as many rows as a launch takes: the calls are walking the buffer
+    const char *next = nullptr;           // the query row behind the last one of this batch
+    std::string queries;                  // the rows as uploaded (the caller's buffer may change under a launch in flight)
+    std::vector<std::pair<RowBuf *, size_t>> staged;   // rows without an arena slot: copied after the wait, from `region`
+    int region = 0;
+    ~RowBatch() { if (done) (void)hipEventDestroy(done); }
+};
 struct RowBuf {
     unsigned char *p = nullptr;
     size_t size = 0;
     int slot = -1;            // >= 0: arena slot, given back when the last holder lets go; -1: heap
+    std::shared_ptr<RowBatch> pending;   // the launch that fills it
 };
 struct RowArena {
     std::mutex mu;            // the free list: rows are released by whichever thread drops the last reference
@@ -796,6 +812,9 @@ static constexpr size_t kRowArenaBytes = size_t(1) << 30;
 
 static void row_release(RowBuf *b)
 {
+    if (b->pending && !b->pending->waited && b->pending->done)   // never hand a slot back under a copy in flight
+        (void)hipEventSynchronize(b->pending->done);
+    b->pending.reset();
     if (b->slot >= 0) {
         std::lock_guard<std::mutex> lock(g_arena.mu);
         g_arena.free_slots.push_back(b->slot);
@@ -854,6 +873,13 @@ static bool row_arena_recarve(size_t size)   // g_seam held
     g_arena.tried = false;
     return true;
 }
+// Free slots of the arena for rows of `size` bytes (-1: the arena does not serve that size, or does not exist yet).
+static long row_arena_free(size_t size)
+{
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    if (!g_arena.base || size > g_arena.slot_bytes) return -1;
+    return static_cast<long>(g_arena.free_slots.size());
+}
 static bool row_arena_too_small(size_t size)
 {
     std::lock_guard<std::mutex> lock(g_arena.mu);
@@ -883,6 +909,12 @@ struct HostSeam {
     uint64_t next_gen = 1, clock = 0, row_hits = 0, row_misses = 0, rows_ahead = 0;
     const unsigned char *last_miss = nullptr;   // where align_hip's previous row miss was (read-ahead heuristic)
     size_t last_miss_stride = 0;
+    static constexpr int kRowRegions = 3;       // device buffers of the row launches in flight (one miss + its successor + one spare)
+    void *d_rowq_ring[kRowRegions] = {}, *d_row_results[kRowRegions] = {};
+    size_t cap_rowq_ring[kRowRegions] = {}, cap_row_results[kRowRegions] = {};
+    std::shared_ptr<RowBatch> region_owner[kRowRegions];
+    unsigned *h_fault = nullptr;                // page-locked: the device's fault word as of each region's last launch
+    uint64_t batch_seq = 0, prefetch_launches = 0;
     size_t row_bytes = 0;
     static constexpr size_t kRowCacheBytes = 1u << 30;
     std::vector<unsigned char> content_copy;   // what d_content holds
@@ -950,8 +982,8 @@ static int seam_row_ahead()
 {
     static const int n = [] {
         const char *e = getenv("BGSA_HIP_ROW_AHEAD");
-        const int v = e ? atoi(e) : 16;     // 10k x 1M through the reference's own pipeline: cal 3.81 / 3.33 / 3.29 / 3.46 s at 1 / 8 / 16 / 32
-        return (v >= 1 && v <= 64) ? v : 16;
+        const int v = e ? atoi(e) : 32;     // 10k x 1M through the reference's own pipeline: cal 1.93 / 1.66 / 1.47 s at 16 / 32 / 64
+        return (v >= 1 && v <= 64) ? v : 32;
     }();
     return n;
 }
@@ -977,6 +1009,16 @@ static int seam_stream()  // g_seam held
         for (void **p : {&g_host.d_content, &g_host.d_peq, &g_host.d_results, &g_host.d_rowq}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
+        }
+        for (int i = 0; i < HostSeam::kRowRegions; i++) {
+            if (g_host.region_owner[i] && !g_host.region_owner[i]->waited && g_host.region_owner[i]->done)
+                (void)hipEventSynchronize(g_host.region_owner[i]->done);
+            g_host.region_owner[i].reset();
+            for (void **p : {&g_host.d_rowq_ring[i], &g_host.d_row_results[i]}) {
+                if (*p) (void)hipFree(*p);
+                *p = nullptr;
+            }
+            g_host.cap_rowq_ring[i] = g_host.cap_row_results[i] = 0;
         }
         g_host.cap_content = g_host.cap_peq = g_host.cap_results = g_host.cap_rowq = 0;
         g_host.content_copy.clear();
@@ -1068,14 +1110,14 @@ int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_up
 
 // BGSA_HIP_SEAM_STATS=1: print the counters of the host seams when the process ends (what the unmodified
 // reference pipeline did with the library: calls, bucket uploads, row-cache hits and misses, time in them).
-static std::atomic<uint64_t> g_row_ns{0}, g_lock_wait_ns{0};
+static std::atomic<uint64_t> g_row_ns{0}, g_lock_wait_ns{0}, g_issue_ns{0}, g_event_ns{0}, g_scan_ns{0}, g_fault_ns{0};
 static void print_seam_stats()
 {
-    fprintf(stderr, "[bgsa_hip] seam calls %llu, Peq uploads %llu (%.1f MB), align_hip row launches %llu (+ %llu rows read ahead) in %.3f s, "
-                    "served from a row: %llu under the lock + %llu from the caller's last row; waited for the seam lock %.3f s\n",
+    fprintf(stderr, "[bgsa_hip] seam calls %llu, Peq uploads %llu (%.1f MB), align_hip row launches %llu on a miss + %llu ahead of the calls (%llu rows read ahead), waited %.3f s for rows, "
+                    "served from a row: %llu under the lock + %llu from the caller's last row; waited for the seam lock %.3f s; issuing %.3f s, in hipEventSynchronize %.3f s, scanning %.3f s, fault check %.3f s\n",
             (unsigned long long)g_host.calls, (unsigned long long)g_host.peq_uploads, g_host.peq_upload_bytes / 1e6,
-            (unsigned long long)g_host.row_misses, (unsigned long long)g_host.rows_ahead, g_row_ns.load() / 1e9, (unsigned long long)g_host.row_hits,
-            (unsigned long long)g_row_fast_hits.load(), g_lock_wait_ns.load() / 1e9);
+            (unsigned long long)g_host.row_misses, (unsigned long long)g_host.prefetch_launches, (unsigned long long)g_host.rows_ahead, g_row_ns.load() / 1e9, (unsigned long long)g_host.row_hits,
+            (unsigned long long)g_row_fast_hits.load(), g_lock_wait_ns.load() / 1e9, g_issue_ns.load() / 1e9, g_event_ns.load() / 1e9, g_scan_ns.load() / 1e9, g_fault_ns.load() / 1e9);
 }
 static void seam_stats_at_exit()
 {
@@ -1294,122 +1336,196 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
             if (r) {
                 g_host.calls++;
                 const size_t r_groups = r->bytes / host_group_bytes, first_group = (peq_host - r->host) / host_group_bytes;
-                std::shared_ptr<RowBuf> row;
-                for (CachedRow &c : g_host.rows)
-                    if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
-                        memcmp(&c.params, &params, sizeof params) == 0 && memcmp(c.query.data(), ref, ref_len) == 0) {
-                        c.stamp = ++g_host.clock;
-                        row = c.scores;
-                        g_host.row_hits++;
-                        break;
+                const size_t n_sub = r_groups * HIP_V_NUM, row_size = n_sub * esz, stride = static_cast<size_t>(ref_len) + 1;
+                auto find_row = [&](const char *qrow_bytes) -> CachedRow * {
+                    for (CachedRow &c : g_host.rows)
+                        if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
+                            memcmp(&c.params, &params, sizeof params) == 0 && memcmp(c.query.data(), qrow_bytes, ref_len) == 0)
+                            return &c;
+                    return nullptr;
+                };
+                // Rows a launch starting at `first` may take: consecutive rows of the malloc_mem() block that holds it,
+                // each closed by its '\n', none of them scored already.
+                auto run_length = [&](const char *first, int limit) {
+                    const uint64_t t_scan = now_ns();
+                    struct Done { uint64_t t; ~Done() { g_scan_ns.fetch_add(now_ns() - t, std::memory_order_relaxed); } } done_{t_scan};
+                    const unsigned char *u = reinterpret_cast<const unsigned char *>(first);
+                    const size_t extent = block_bytes_after(first);
+                    int n = 0;
+                    while (n < limit && static_cast<size_t>(n + 1) * stride <= extent && u[static_cast<size_t>(n) * stride + ref_len] == '\n' &&
+                           !find_row(first + static_cast<size_t>(n) * stride))
+                        n++;
+                    return n;
+                };
+                auto wait_batch = [&](const std::shared_ptr<RowBatch> &bt) {
+                    if (!bt || bt->waited) return;
+                    const uint64_t t_ev = now_ns();
+                    bool ok = hipEventSynchronize(bt->done) == hipSuccess;
+                    g_event_ns.fetch_add(now_ns() - t_ev, std::memory_order_relaxed);
+                    for (size_t j = 0; ok && j < bt->staged.size(); j++) {   // rows without an arena slot: through the staging buffer
+                        ok = hipMemcpyAsync(g_host.h_stage, static_cast<unsigned char *>(g_host.d_row_results[bt->region]) + bt->staged[j].second,
+                                            row_size, hipMemcpyDeviceToHost, g_host.stream) == hipSuccess &&
+                             hipStreamSynchronize(g_host.stream) == hipSuccess;
+                        if (ok) memcpy(bt->staged[j].first->p, g_host.h_stage, row_size);
                     }
-                if (!row) {
-                    g_host.row_misses++;
-                    const uint64_t t_row = now_ns();
-                    hipStream_t s = g_host.stream;
-                    const size_t n_sub = r_groups * HIP_V_NUM, row_size = n_sub * esz, stride = static_cast<size_t>(ref_len) + 1;
-                    // Read-ahead: the reference's grid walks the query buffer row after row (cal_cpu.c:63-84), so when this
-                    // miss sits near the previous one inside a malloc_mem() block, the rows behind it are scored in the same
-                    // launch.  A row is only ever served for a query with the same bytes, so a wrong guess costs time, never
-                    // results.
-                    int n_rows = 1;
-                    const unsigned char *uref = reinterpret_cast<const unsigned char *>(ref);
-                    const size_t extent = block_bytes_after(ref);
-                    const bool near_last = g_host.last_miss && g_host.last_miss_stride == stride &&
-                                           (uref > g_host.last_miss ? static_cast<size_t>(uref - g_host.last_miss)
-                                                                    : static_cast<size_t>(g_host.last_miss - uref)) <= 64 * stride;
-                    auto cached = [&](const char *qrow_bytes) {   // a row another launch has scored already ends the run
-                        for (const CachedRow &c : g_host.rows)
-                            if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
-                                memcmp(c.query.data(), qrow_bytes, ref_len) == 0 && memcmp(&c.params, &params, sizeof params) == 0)
-                                return true;
-                        return false;
-                    };
-                    if (near_last && extent >= stride && uref[ref_len] == '\n')
-                        while (n_rows < seam_row_ahead() && static_cast<size_t>(n_rows + 1) * stride <= extent &&
-                               uref[static_cast<size_t>(n_rows) * stride + ref_len] == '\n' &&
-                               !cached(ref + static_cast<size_t>(n_rows) * stride))
-                            n_rows++;
-                    g_host.last_miss = uref;
-                    g_host.last_miss_stride = stride;
-                    if (g_host.reserve(&g_host.d_rowq, &g_host.cap_rowq, static_cast<size_t>(n_rows) * stride + 16) ||
-                        g_host.reserve(&g_host.d_results, &g_host.cap_results, static_cast<size_t>(n_rows) * row_size))
+                    bt->staged.clear();
+                    bt->waited = true;
+                    if (!ok) {
+                        if (g_last_error.empty()) set_error_text("align_hip: scoring the query rows failed");
                         die("align_hip");
-                    std::string qrow;
-                    const void *q_src = ref;
-                    if (n_rows == 1) {   // a lone row may not be followed by its terminator in the caller's memory
-                        qrow.assign(ref, ref + ref_len);
-                        qrow.push_back('\n');
-                        q_src = qrow.data();
                     }
-                    // room for the new rows: the least recently used ones go first
+                    const uint64_t t_f = now_ns();
+                    if (g_host.h_fault && g_host.h_fault[bt->region] != 0 && bgsa_hip_stream_faults(1) != 0) die("align_hip");
+                    g_fault_ns.fetch_add(now_ns() - t_f, std::memory_order_relaxed);
+                };
+                // One launch: n_rows query rows starting at `first` against the whole bucket; kernel on the seam's stream,
+                // the rows down on its copy stream straight into their arena slots.  Returns with everything queued.
+                auto issue = [&](const char *first, int n_rows, bool rows_in_block) -> std::shared_ptr<RowBatch> {
+                    const uint64_t t_issue = now_ns();
+                    auto bt = std::make_shared<RowBatch>();
+                    bt->region = static_cast<int>(g_host.batch_seq++ % HostSeam::kRowRegions);
+                    const int reg = bt->region;
+                    wait_batch(g_host.region_owner[reg]);     // the launch that used these device buffers before
+                    bt->queries.reserve(static_cast<size_t>(n_rows) * stride);
+                    for (int j = 0; j < n_rows; j++) {        // a lone row may not be followed by its terminator in the caller's memory
+                        bt->queries.append(first + static_cast<size_t>(j) * stride, ref_len);
+                        bt->queries.push_back('\n');
+                    }
+                    bt->full = n_rows == seam_row_ahead();
+                    bt->next = rows_in_block ? first + static_cast<size_t>(n_rows) * stride : nullptr;
                     while (!g_host.rows.empty() && g_host.row_bytes + static_cast<size_t>(n_rows) * row_size > HostSeam::kRowCacheBytes) {
+                        size_t oldest = 0;                    // room for the new rows: the least recently used ones go first
+                        for (size_t j = 1; j < g_host.rows.size(); j++)
+                            if (g_host.rows[j].stamp < g_host.rows[oldest].stamp) oldest = j;
+                        g_host.row_bytes -= g_host.rows[oldest].scores->size;
+                        g_host.rows.erase(g_host.rows.begin() + oldest);
+                    }
+                    // ... and the cache never holds more rows than the arena has slots: a row without a slot has to be
+                    // staged and copied, under the lock, while the next launch waits
+                    for (long free_slots = row_arena_free(row_size); free_slots >= 0 && free_slots < n_rows && !g_host.rows.empty();
+                         free_slots = row_arena_free(row_size)) {
                         size_t oldest = 0;
                         for (size_t j = 1; j < g_host.rows.size(); j++)
                             if (g_host.rows[j].stamp < g_host.rows[oldest].stamp) oldest = j;
                         g_host.row_bytes -= g_host.rows[oldest].scores->size;
                         g_host.rows.erase(g_host.rows.begin() + oldest);
                     }
-                    if (row_arena_too_small(row_size)) {   // a bigger bucket than the arena was carved for: start it over
+                    if (row_arena_too_small(row_size)) {      // a bigger bucket than the arena was carved for: start it over
                         g_host.rows.clear();
                         g_host.row_bytes = 0;
                         last.scores.reset();
                         (void)row_arena_recarve(row_size);
                     }
+                    hipStream_t s = g_host.stream;
+                    bool ok = g_host.reserve(&g_host.d_rowq_ring[reg], &g_host.cap_rowq_ring[reg], bt->queries.size() + 16) == BGSA_HIP_OK &&
+                              g_host.reserve(&g_host.d_row_results[reg], &g_host.cap_row_results[reg], static_cast<size_t>(n_rows) * row_size) == BGSA_HIP_OK &&
+                              hipEventCreateWithFlags(&bt->done, hipEventDisableTiming) == hipSuccess &&
+                              hipMemcpyAsync(g_host.d_rowq_ring[reg], bt->queries.data(), bt->queries.size(), hipMemcpyHostToDevice, s) == hipSuccess &&
+                              bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_rowq_ring[reg]),
+                                                          static_cast<const hip_read_t *>(r->dev), g_host.d_row_results[reg], ref_len, read_len,
+                                                          static_cast<int64_t>(n_sub), 0, n_rows, w_dev, nullptr, 0, s) == BGSA_HIP_OK &&
+                              hipEventRecord(g_host.tile_done[0], s) == hipSuccess &&
+                              hipStreamWaitEvent(g_host.copy_stream, g_host.tile_done[0], 0) == hipSuccess;
                     std::vector<std::shared_ptr<RowBuf>> bufs(n_rows);
-                    std::vector<bool> direct(n_rows);
-                    bool any_staged = false;
-                    for (int j = 0; j < n_rows; j++) {
+                    for (int j = 0; ok && j < n_rows; j++) {
                         bool pinned = false;
                         bufs[j] = row_take(row_size, &pinned);
-                        direct[j] = pinned;
-                        any_staged = any_staged || !pinned;
-                    }
-                    if (any_staged && g_host.cap_stage < row_size) {
-                        if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
-                        g_host.h_stage = nullptr;
-                        g_host.cap_stage = 0;
-                        if (hipHostMalloc(&g_host.h_stage, row_size, hipHostMallocPortable) != hipSuccess) {
-                            set_error_text("align_hip: hipHostMalloc (row staging) failed");
-                            die("align_hip");
+                        bufs[j]->pending = bt;
+                        if (pinned) {
+                            ok = hipMemcpyAsync(bufs[j]->p, static_cast<unsigned char *>(g_host.d_row_results[reg]) + static_cast<size_t>(j) * row_size,
+                                                row_size, hipMemcpyDeviceToHost, g_host.copy_stream) == hipSuccess;
+                        } else {
+                            bt->staged.emplace_back(bufs[j].get(), static_cast<size_t>(j) * row_size);
+                            if (g_host.cap_stage < row_size) {
+                                if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
+                                g_host.h_stage = nullptr;
+                                g_host.cap_stage = 0;
+                                ok = hipHostMalloc(&g_host.h_stage, row_size, hipHostMallocPortable) == hipSuccess;
+                                if (ok) g_host.cap_stage = row_size;
+                            }
                         }
-                        g_host.cap_stage = row_size;
                     }
-                    bool ok = hipMemcpyAsync(g_host.d_rowq, q_src, static_cast<size_t>(n_rows) * stride, hipMemcpyHostToDevice, s) == hipSuccess &&
-                              bgsa_hip_cal_align_score_ex(&params, static_cast<const char *>(g_host.d_rowq),
-                                                          static_cast<const hip_read_t *>(r->dev), g_host.d_results, ref_len, read_len,
-                                                          static_cast<int64_t>(n_sub), 0, n_rows, w_dev, nullptr, 0, s) == BGSA_HIP_OK;
-                    for (int j = 0; ok && j < n_rows; j++)
-                        if (direct[j])
-                            ok = hipMemcpyAsync(bufs[j]->p, static_cast<unsigned char *>(g_host.d_results) + static_cast<size_t>(j) * row_size,
-                                                row_size, hipMemcpyDeviceToHost, s) == hipSuccess;
-                    ok = ok && hipStreamSynchronize(s) == hipSuccess;
-                    for (int j = 0; ok && j < n_rows; j++)
-                        if (!direct[j]) {   // no arena slot: through the staging buffer, one row at a time
-                            ok = hipMemcpyAsync(g_host.h_stage, static_cast<unsigned char *>(g_host.d_results) + static_cast<size_t>(j) * row_size,
-                                                row_size, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-                            if (ok) memcpy(bufs[j]->p, g_host.h_stage, row_size);
-                        }
+                    // the device's fault word travels behind the rows (reading it with a blocking copy would wait for the
+                    // launch already queued behind this one, and the overlap would be gone)
+                    if (ok && !g_host.h_fault)
+                        ok = hipHostMalloc(reinterpret_cast<void **>(&g_host.h_fault), 64, hipHostMallocPortable) == hipSuccess;
+                    unsigned *d_fault = ok ? device_fault_word() : nullptr;
+                    ok = ok && d_fault &&
+                         hipMemcpyAsync(&g_host.h_fault[reg], d_fault, sizeof(unsigned), hipMemcpyDeviceToHost, g_host.copy_stream) == hipSuccess;
+                    ok = ok && hipEventRecord(bt->done, g_host.copy_stream) == hipSuccess;
                     if (!ok) {
-                        if (g_last_error.empty()) set_error_text("align_hip: scoring the query rows failed");
+                        if (g_last_error.empty()) set_error_text("align_hip: launching the query rows failed");
                         die("align_hip");
                     }
-                    if (bgsa_hip_stream_faults(1) != 0) die("align_hip");
+                    g_host.region_owner[reg] = bt;
                     for (int j = 0; j < n_rows; j++) {
                         CachedRow c;
                         c.range_gen = r->gen;
                         c.params = params;
                         c.read_len = read_len;
-                        c.query.assign(ref + static_cast<size_t>(j) * stride, ref + static_cast<size_t>(j) * stride + ref_len);
+                        c.query.assign(first + static_cast<size_t>(j) * stride, first + static_cast<size_t>(j) * stride + ref_len);
                         c.scores = bufs[j];
                         c.stamp = ++g_host.clock;
                         g_host.row_bytes += row_size;
                         g_host.rows.push_back(std::move(c));
                     }
+                    g_issue_ns.fetch_add(now_ns() - t_issue, std::memory_order_relaxed);
+                    return bt;
+                };
+                // The calls are walking the buffer: keep one launch ahead of them.
+                auto chain = [&](const std::shared_ptr<RowBatch> &bt) {
+                    if (!bt || bt->chained) return;
+                    bt->chained = true;
+                    if (!bt->full || !bt->next || seam_row_ahead() < 2) return;
+                    const int n = run_length(bt->next, seam_row_ahead());
+                    if (n > 0) {
+                        issue(bt->next, n, true);
+                        g_host.prefetch_launches++;
+                        g_host.rows_ahead += static_cast<uint64_t>(n);
+                    }
+                };
+                std::shared_ptr<RowBuf> row;
+                if (CachedRow *c = find_row(ref)) {
+                    c->stamp = ++g_host.clock;
+                    row = c->scores;
+                    g_host.row_hits++;
+                    if (row->pending) {
+                        std::shared_ptr<RowBatch> bt = row->pending;
+                        const uint64_t t_row = now_ns();
+                        chain(bt);           // may grow g_host.rows: `c` is not used below
+                        wait_batch(bt);
+                        g_row_ns.fetch_add(now_ns() - t_row, std::memory_order_relaxed);
+                    }
+                }
+                if (!row) {
+                    g_host.row_misses++;
+                    const uint64_t t_row = now_ns();
+                    // Read-ahead: the reference's grid walks the query buffer row after row (cal_cpu.c:63-84), so when this
+                    // miss sits near the previous one inside a malloc_mem() block, the rows behind it are scored in the same
+                    // launch and the launch behind that one is issued at once.  A row is only ever served for a query with
+                    // the same bytes, so a wrong guess costs time, never results.
+                    const unsigned char *uref = reinterpret_cast<const unsigned char *>(ref);
+                    const bool near_last = g_host.last_miss && g_host.last_miss_stride == stride &&
+                                           (uref > g_host.last_miss ? static_cast<size_t>(uref - g_host.last_miss)
+                                                                    : static_cast<size_t>(g_host.last_miss - uref)) <= 64 * stride;
+                    int n_rows = near_last ? run_length(ref, seam_row_ahead()) : 0;
+                    const bool in_block = n_rows >= 1;
+                    if (n_rows < 1) n_rows = 1;
+                    g_host.last_miss = uref;
+                    g_host.last_miss_stride = stride;
+                    std::shared_ptr<RowBatch> bt = issue(ref, n_rows, in_block);
                     g_host.rows_ahead += static_cast<uint64_t>(n_rows - 1);
-                    row = bufs[0];
+                    chain(bt);
+                    wait_batch(bt);
+                    CachedRow *c = find_row(ref);
+                    if (!c) {
+                        set_error_text("align_hip: the row just scored is not in the cache");
+                        die("align_hip");
+                    }
+                    row = c->scores;
                     g_row_ns.fetch_add(now_ns() - t_row, std::memory_order_relaxed);
                 }
+                row->pending.reset();   // served: nothing in flight behind this buffer any more
                 last.epoch = g_range_epoch.load(std::memory_order_acquire);
                 last.range_host = r->host;
                 last.range_bytes = r->bytes;

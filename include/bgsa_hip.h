@@ -168,8 +168,9 @@ int bgsa_hip_seam_stats(uint64_t *calls, uint64_t *peq_uploads, uint64_t *peq_up
  * against the whole bucket in one launch and keeps that row (page-locked host memory, at most 1 GiB of
  * rows, least recently used first out); the other calls for the same query, bucket and parameters copy
  * their chunk out of it.  When the misses walk a malloc_mem() query buffer row after row, the rows behind
- * the requested one that no launch has scored yet join its launch (BGSA_HIP_ROW_AHEAD, default 16 rows per
- * launch, 1 = off); a row is only served for a query with the same bytes.  hip_cal_align_score scores its
+ * the requested one that no launch has scored yet join its launch and the next launch is issued ahead of the
+ * calls (BGSA_HIP_ROW_AHEAD, default 32 rows per launch, 1 = off); a row is only served for a query with the
+ * same bytes.  hip_cal_align_score scores its
  * block in BGSA_HIP_SEAM_TILES (default 8) query tiles and copies tile t out while tile t+1 runs.
  * hits / misses (= launches) since process start. */
 int bgsa_hip_row_cache_stats(uint64_t *hits, uint64_t *misses);
