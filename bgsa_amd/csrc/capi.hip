@@ -1337,6 +1337,9 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 g_host.calls++;
                 const size_t r_groups = r->bytes / host_group_bytes, first_group = (peq_host - r->host) / host_group_bytes;
                 const size_t n_sub = r_groups * HIP_V_NUM, row_size = n_sub * esz, stride = static_cast<size_t>(ref_len) + 1;
+                // rows per launch: two launches in flight must fit the row arena several times over (huge buckets: fewer rows)
+                const int ahead = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(seam_row_ahead()),
+                                                                                     kRowArenaBytes / std::max<size_t>(row_size, 1) / 4)));
                 auto find_row = [&](const char *qrow_bytes) -> CachedRow * {
                     for (CachedRow &c : g_host.rows)
                         if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&
@@ -1391,7 +1394,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                         bt->queries.append(first + static_cast<size_t>(j) * stride, ref_len);
                         bt->queries.push_back('\n');
                     }
-                    bt->full = n_rows == seam_row_ahead();
+                    bt->full = n_rows == ahead;
                     bt->next = rows_in_block ? first + static_cast<size_t>(n_rows) * stride : nullptr;
                     while (!g_host.rows.empty() && g_host.row_bytes + static_cast<size_t>(n_rows) * row_size > HostSeam::kRowCacheBytes) {
                         size_t oldest = 0;                    // room for the new rows: the least recently used ones go first
@@ -1476,8 +1479,8 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 auto chain = [&](const std::shared_ptr<RowBatch> &bt) {
                     if (!bt || bt->chained) return;
                     bt->chained = true;
-                    if (!bt->full || !bt->next || seam_row_ahead() < 2) return;
-                    const int n = run_length(bt->next, seam_row_ahead());
+                    if (!bt->full || !bt->next || ahead < 2) return;
+                    const int n = run_length(bt->next, ahead);
                     if (n > 0) {
                         issue(bt->next, n, true);
                         g_host.prefetch_launches++;
@@ -1508,7 +1511,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                     const bool near_last = g_host.last_miss && g_host.last_miss_stride == stride &&
                                            (uref > g_host.last_miss ? static_cast<size_t>(uref - g_host.last_miss)
                                                                     : static_cast<size_t>(g_host.last_miss - uref)) <= 64 * stride;
-                    int n_rows = near_last ? run_length(ref, seam_row_ahead()) : 0;
+                    int n_rows = near_last ? run_length(ref, ahead) : 0;
                     const bool in_block = n_rows >= 1;
                     if (n_rows < 1) n_rows = 1;
                     g_host.last_miss = uref;
