@@ -812,8 +812,12 @@ static constexpr size_t kRowArenaBytes = size_t(1) << 30;
 
 static void row_release(RowBuf *b)
 {
-    if (b->pending && !b->pending->waited && b->pending->done)   // never hand a slot back under a copy in flight
-        (void)hipEventSynchronize(b->pending->done);
+    if (b->pending && !b->pending->waited) {   // dropped with its launch still in flight (eviction, bucket rewritten):
+        if (b->pending->done) (void)hipEventSynchronize(b->pending->done);   // never hand a slot back under a copy in flight
+        auto &st = b->pending->staged;         // and the launch must not copy into this buffer later (g_seam is held here:
+        for (size_t j = 0; j < st.size();)     // only served rows, whose `pending` is gone, are released by other threads)
+            if (st[j].first == b) st.erase(st.begin() + j); else j++;
+    }
     b->pending.reset();
     if (b->slot >= 0) {
         std::lock_guard<std::mutex> lock(g_arena.mu);
@@ -835,6 +839,9 @@ static std::shared_ptr<RowBuf> row_take(size_t size, bool *pinned)   // g_seam h
             g_arena.tried = true;
             const size_t slot = (size + 4095) & ~size_t(4095);
             size_t bytes = std::min(kRowArenaBytes, std::max(size_t(64) << 20, 512 * slot));   // small buckets: a small arena
+            if (const char *e = getenv("BGSA_HIP_ROW_ARENA")) {   // "0": no arena — every row takes the staged path (tests)
+                if (e[0] == '0') bytes = 0;
+            }
             while (bytes >= 4 * slot && bytes >= (size_t(64) << 20)) {
                 void *m = nullptr;
                 if (hipHostMalloc(&m, bytes, hipHostMallocPortable) == hipSuccess && m) {

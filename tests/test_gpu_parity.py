@@ -644,6 +644,52 @@ def test_align_hip_reads_ahead_in_a_query_buffer(oracle):
         L.free_mem(block)
 
 
+_ROW_SCRIPT = r"""
+import sys, ctypes, numpy as np
+sys.path.insert(0, sys.argv[1])
+import bgsa_amd as B, oracle as O
+L = B.lib()
+nq, length = 70, 150
+q = O.gen_reads(91, nq, length); s, _ = B.pad_rows(O.gen_reads(92, 64 * 9, length))
+s[:nq] = O.mutate(q, np.arange(nq) % 9, 93)
+want = O.myers64(q, s)
+L.bgsa_hip_select_algorithm(B.ALGO_MYERS); L.init_mapping_table()
+table = np.ctypeslib.as_array((ctypes.c_uint32 * 128).in_dll(L, "mapping_table"))
+sbuf = B.rows_to_buffer(s)
+seq = B.SeqT(len=length, size=sbuf.size, count=s.shape[0], extra_size=0, extra_count=0, content=sbuf.ctypes.data)
+qb = B.rows_to_buffer(q); keep = qb == 10; qm = table[qb].astype(np.uint8); qm[keep] = 10
+wn, n = 5, s.shape[0]
+peq = np.zeros(B.group_words(B.ALGO_MYERS, wn) * (n // 64), dtype=np.uint32)
+L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+block = L.malloc_mem(1 << 16)
+buf = np.ctypeslib.as_array(ctypes.cast(block, ctypes.POINTER(ctypes.c_uint8)), shape=(1 << 16,)); buf[:] = 0; buf[: qm.size] = qm
+out = np.zeros((nq, n), dtype=np.int16)
+order = list(range(nq)) + [5, 40, 69, 0]          # a walk, then a few rows again
+for i in order:
+    L.align_hip(block + i * (length + 1), peq.ctypes.data, length, length, wn, n // 64, i * (n // 64), out.ctypes.data, None)
+assert np.array_equal(out, want)
+h, m = ctypes.c_uint64(), ctypes.c_uint64(); L.bgsa_hip_row_cache_stats(ctypes.byref(h), ctypes.byref(m))
+print("rows ok", m.value)
+"""
+
+
+@pytest.mark.parametrize("env", [{"BGSA_HIP_ROW_ARENA": "0"},                          # no page-locked arena: every row staged and copied
+                                 {"BGSA_HIP_ROW_AHEAD": "1"},                          # one row per launch, nothing ahead of the calls
+                                 {"BGSA_HIP_ROW_AHEAD": "7", "BGSA_HIP_ROW_ARENA": "0"},
+                                 {"BGSA_HIP_ROW_AHEAD": "64"}])
+def test_align_hip_row_cache_variants(env):
+    """align_hip walking a query buffer with the row cache's fallbacks and knobs (read once per process: child processes)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(B.__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, "-c", _ROW_SCRIPT, str(root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "rows ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    launches = int(p.stdout.split()[-1])
+    assert launches == (70 if env.get("BGSA_HIP_ROW_AHEAD") == "1" else 2)      # without read-ahead one launch per query; else query 0, then query 1 with its followers
+
+
 def test_wrong_word_num_is_refused(oracle):
     # the kernels index the blocks with the caller's word_num: anything but the layout's own value is an error
     import torch
