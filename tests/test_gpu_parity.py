@@ -690,6 +690,58 @@ def test_align_hip_row_cache_variants(env):
     assert launches == (70 if env.get("BGSA_HIP_ROW_AHEAD") == "1" else 2)      # without read-ahead one launch per query; else query 0, then query 1 with its followers
 
 
+def test_align_hip_from_many_threads(oracle):
+    """Eight host threads hammer align_hip with random (query, chunk) requests on one bucket, as an OpenMP team with a
+    dynamic schedule would: every chunk must come back right whatever the interleaving of misses, launches kept ahead
+    of the calls, evictions and each thread's own last-row shortcut."""
+    import threading
+    L = B.lib()
+    nq, length, groups = 90, 150, 8
+    q = oracle.gen_reads(101, nq, length)
+    s, _ = B.pad_rows(oracle.gen_reads(102, 64 * groups, length))
+    s[:nq] = oracle.mutate(q, np.arange(nq) % 9, 103)
+    want = oracle.myers64(q, s)
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.init_mapping_table()
+    sbuf, seq, qmapped = _host_seam_inputs(L, q, s)
+    wn, n = 5, s.shape[0]
+    gw = B.group_words(B.ALGO_MYERS, wn)
+    peq = np.zeros(gw * groups, dtype=np.uint32)
+    L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, n)
+    block = L.malloc_mem(1 << 16)
+    errors = []
+    try:
+        qbuf = np.ctypeslib.as_array(ctypes.cast(block, ctypes.POINTER(ctypes.c_uint8)), shape=(1 << 16,))
+        qbuf[:] = 0
+        qbuf[: qmapped.size] = qmapped
+
+        def worker(seed):
+            rng = np.random.default_rng(seed)
+            res = np.zeros(n, dtype=np.int16)
+            try:
+                for it in range(600):
+                    i = int(rng.integers(0, nq)) if it % 3 else (it // 3 + seed * 11) % nq     # random and walking requests mixed
+                    j = int(rng.integers(0, groups))
+                    c = int(rng.integers(1, groups - j + 1))
+                    res[:] = 77
+                    L.align_hip(block + i * (length + 1), peq[gw * j:].ctypes.data, length, length, wn, c, j, res.ctypes.data, None)
+                    if not np.array_equal(res[64 * j: 64 * (j + c)], want[i, 64 * j: 64 * (j + c)]) or (res[: 64 * j] != 77).any() or (res[64 * (j + c):] != 77).any():
+                        errors.append((seed, it, i, j, c))
+                        return
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:3]
+    finally:
+        L.bgsa_hip_bucket_release(None)
+        L.free_mem(block)
+
+
 def test_wrong_word_num_is_refused(oracle):
     # the kernels index the blocks with the caller's word_num: anything but the layout's own value is an error
     import torch
