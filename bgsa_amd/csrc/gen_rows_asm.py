@@ -918,12 +918,15 @@ def main() -> int:
         parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_body(nw, 1), 2 * nw, nw))
     parts.append("\n// Short subjects: the row is so short that the scalar dispatch bounds the loop, so a stream token\n"
                  "// carries two rows (bgsa_common.h: pair_stream_window).\n"
-                 "template <int NW>\n"
-                 "__device__ __forceinline__ int myers_pair_rows_asm(uint32_t (&state)[2 * NW],\n"
-                 "                                                    const uint32_t (&P)[5][NW],\n"
+                 "// G = 2: two subject groups per wave — twice the vector work behind every dispatch, and these bodies are so\n"
+                 "// small that the registers of two groups still leave eight waves per SIMD.\n"
+                 "template <int NW, int G>\n"
+                 "__device__ __forceinline__ int myers_pair_rows_asm(uint32_t (&state)[2 * G * NW],\n"
+                 "                                                    const uint32_t (&P)[5][G * NW],\n"
                  "                                                    const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PAIR_NW:
-        parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}", R.myers_body(nw, 1), 2 * nw, nw))
+        for g in (1, 2):
+            parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}, {g}", R.myers_body(nw, g), 2 * g * nw, g * nw))
     parts.append("\n// Semi-global (generator -m 0 -s): rows_ir.py: myers_semi_body — the subject right-aligned in its NW words,\n"
                  "// state = {VP, VN} x NW, then D[i][n] (running) and its minimum; 10 VALU per word + 3 per row.\n"
                  "template <int NW>\n"

@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
         int left;
-        if constexpr (G == 1 && NW <= kPairMaxWords)  // short rows: two per stream token (launch_asm packs it so)
-            left = myers_pair_rows_asm<NW>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+        if constexpr (NW <= kPairMaxWords)  // short rows: two per stream token (launch_asm packs it so)
+            left = myers_pair_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
         else
             left = myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
         note_stream_fault(fault_word, left);
@@ -571,6 +571,16 @@ int myers_impl()
     return impl;
 }
 
+// Subject groups per wave of the two-rows-per-token kernels (<= 64 bp): 2 by default, BGSA_MYERS_PAIR_GROUPS=1 for the A/B.
+static int pair_groups()
+{
+    static const int g = [] {
+        const char *e = getenv("BGSA_MYERS_PAIR_GROUPS");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return g;
+}
+
 template <int NW, int G>
 int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
@@ -585,7 +595,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
         set_error_text("myers: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    constexpr bool kPairs = G == 1 && NW <= kPairMaxWords;
+    constexpr bool kPairs = NW <= kPairMaxWords;
     if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream)
                         : launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream))
         return rc;
@@ -818,7 +828,8 @@ const char *myers_kernel_name(int word_num, int semi_global)
         return name;
     }
     if (myers_impl() == 0 && pick_peq_nw(word_num) > 0)
-        snprintf(name, sizeof name, "myers_global_asm_kernel<%d, 1>", pick_peq_nw(word_num));
+        snprintf(name, sizeof name, "myers_global_asm_kernel<%d, %d>", pick_peq_nw(word_num),
+                 (word_num <= kPairMaxWords && pair_groups() == 2) ? 2 : 1);
     else if (myers_impl() == 0 && pick_planes_nw(word_num) > 0)
         snprintf(name, sizeof name, "myers_global_planes_kernel<%d>", pick_planes_nw(word_num));
     else
@@ -913,6 +924,13 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         }
     }
     if (myers_impl() == 0) {
+        if (word_num <= kPairMaxWords && pair_groups() == 2 && read_count >= 2 * kLanes) {   // short subjects: two groups per wave
+            if (word_num == 1)
+                return launch_asm<1, 2>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
+                                        d_workspace, stream);
+            return launch_asm<2, 2>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
+                                    d_workspace, stream);
+        }
         switch (pick_peq_nw(word_num)) {
 #define BGSA_ASM_CASE(N)                                                                        \
     case N:                                                                                     \

@@ -898,6 +898,23 @@ def test_myers_positive_distance(oracle, slen):
     assert np.array_equal(pos, -oracle.dp_edit(q, s).astype(np.int32))   # dp_edit follows the reference sign: -distance
 
 
+@pytest.mark.parametrize("slen", [1, 17, 32, 33, 50, 64])
+@pytest.mark.parametrize("ns", [128, 192, 64 * 5 + 9])
+def test_short_subjects_two_groups_per_wave(oracle, slen, ns):
+    """Subjects of <= 64 bp run two rows per stream token AND two subject groups per wave (myers_global_asm_kernel<NW, 2>):
+    even and odd group counts (the last wave then holds one live group), query lengths on both sides of the subject's."""
+    for qlen in (slen, 2 * slen + 3, max(1, slen // 2)):
+        q = oracle.gen_reads(4000 + slen + qlen, 7, qlen)
+        s = oracle.gen_reads(4100 + slen + ns, ns, slen)
+        m = min(qlen, slen)
+        s[:40, :m] = oracle.mutate(q[np.arange(40) % 7][:, :m], np.arange(40) % 5, 4200 + slen)
+        a = B.DeviceAligner(B.ALGO_MYERS)
+        a.set_queries(q)
+        a.set_subjects(s)
+        assert a.kernel_name().startswith("myers_global_asm_kernel<%d, 2>" % (1 if slen <= 32 else 2))
+        assert np.array_equal(a.score().cpu().numpy()[:, :ns], oracle.myers64(q, s))
+
+
 # ---- semi-global Myers (generator -m 0 -s): the subject end to end inside the query --------------------
 @pytest.mark.parametrize("qlen,slen", [(200, 60), (150, 150), (33, 97), (1, 1), (500, 250), (1000, 300), (700, 1000), (300, 1024),
                                        (64, 32), (90, 33), (400, 768), (400, 769), (900, 800), (1300, 1100), (3000, 2500), (200, 4000),
