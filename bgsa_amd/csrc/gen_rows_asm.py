@@ -31,7 +31,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 import rows_ir as R  # noqa: E402
 
-MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24]  # Peq masks resident: 10 VALU per word
+MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25]  # Peq masks resident: 10 VALU per word (25 words = 253 VGPRs, the last width with two waves per SIMD)
 MYERS_PEQ_BLOCK_NW = [12, 14, 16, 18, 20]  # column blocks with resident Peq planes (20 words: 238 VGPRs; 22 would need 256)
 MYERS_PAIR_NW = [1, 2]  # two rows per stream token: the 10-20 VALU row cannot hide the scalar dispatch
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 }
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
-constexpr int kPeqMaxWords = 24;  // default of myers_peq_max_words(): measured faster than the code planes up to here
+constexpr int kPeqMaxWords = 25;  // default of myers_peq_max_words(): measured faster than the code planes up to here
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"
 
@@ -779,7 +779,7 @@ int myers_peq_max_words()
     static const int limit = [] {
         const char *e = getenv("BGSA_MYERS_PEQ_MAX_WORDS");
         const int v = e ? atoi(e) : kPeqMaxWords;
-        return (v >= 8 && v <= 24) ? v : kPeqMaxWords;
+        return (v >= 8 && v <= 25) ? v : kPeqMaxWords;
     }();
     return limit;
 }
@@ -798,7 +798,7 @@ int pick_semi_planes_nw(int word_num)
 int pick_peq_nw(int word_num)
 {
     if (word_num > myers_peq_max_words()) return -1;
-    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24})
+    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25})
         if (nw >= word_num) return nw;
     return -1;
 }
@@ -864,7 +864,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
                 BGSA_SEMI_CASE(1) BGSA_SEMI_CASE(2) BGSA_SEMI_CASE(3) BGSA_SEMI_CASE(4) BGSA_SEMI_CASE(5)
                 BGSA_SEMI_CASE(6) BGSA_SEMI_CASE(7) BGSA_SEMI_CASE(8) BGSA_SEMI_CASE(10) BGSA_SEMI_CASE(12)
                 BGSA_SEMI_CASE(14) BGSA_SEMI_CASE(16) BGSA_SEMI_CASE(18) BGSA_SEMI_CASE(20) BGSA_SEMI_CASE(22)
-                BGSA_SEMI_CASE(24)
+                BGSA_SEMI_CASE(24) BGSA_SEMI_CASE(25)
 #undef BGSA_SEMI_CASE
             default: break;
             }
@@ -939,7 +939,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             BGSA_ASM_CASE(1) BGSA_ASM_CASE(2) BGSA_ASM_CASE(3) BGSA_ASM_CASE(4) BGSA_ASM_CASE(5)
             BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8) BGSA_ASM_CASE(10) BGSA_ASM_CASE(12)
             BGSA_ASM_CASE(14) BGSA_ASM_CASE(16) BGSA_ASM_CASE(18) BGSA_ASM_CASE(20) BGSA_ASM_CASE(22)
-            BGSA_ASM_CASE(24)
+            BGSA_ASM_CASE(24) BGSA_ASM_CASE(25)
 #undef BGSA_ASM_CASE
         default: break;
         }

@@ -115,7 +115,7 @@ int bgsa_hip_score_set(int index, int *match, int *mismatch, int *gap, int *valu
  *     row.  Any compiled score set, any length.
  *   BGSA_ALGO_MYERS (MyersGenerator.java:56-223 genSemiGlobal): the SUBJECT is aligned end to end inside
  *     the query (D[0][y] = 0, result = -min over y of D[slen][y]); any length (generated-asm kernels:
- *     resident Peq planes up to 768 bp, code planes up to 1024 bp, column blocks beyond).
+ *     resident Peq planes up to 800 bp, code planes up to 1024 bp, column blocks beyond).
  *   BGSA_ALGO_BANDED: not defined, BGSA_HIP_EUNSUPPORTED.
  * Process-global like the score ints. */
 enum { BGSA_ALIGN_GLOBAL = 0, BGSA_ALIGN_SEMIGLOBAL = 1 };

@@ -936,14 +936,15 @@ def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
 
 
 def test_myers_semiglobal_kernel_families(oracle):
-    # generated-asm kernels: resident Peq planes up to 768 bp, code planes up to 1024 bp, column blocks beyond — any length
+    # generated-asm kernels: resident Peq planes up to 800 bp, code planes up to 1024 bp, column blocks beyond — any length
     L = B.lib()
     L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
     L.bgsa_hip_select_alignment(1)
     try:
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 5).startswith(b"myers_semi_asm_kernel<5>")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 24).startswith(b"myers_semi_asm_kernel<24>")
-        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 25).startswith(b"myers_semi_planes_kernel<26>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 25).startswith(b"myers_semi_asm_kernel<25>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 26).startswith(b"myers_semi_planes_kernel<26>")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 32).startswith(b"myers_semi_planes_kernel<32>")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 33).startswith(b"myers_blocked_kernel<")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 125).startswith(b"myers_blocked_kernel<18, true, true>")
