@@ -92,9 +92,9 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
         import rows_ir as R
     except Exception:
         return None
-    if algo == B.ALGO_MYERS and wn <= 25:      # Peq planes resident (myers_global_asm_kernel)
-        nw = wn if wn <= 8 else (25 if wn == 25 else next(n for n in range(10, 25, 2) if n >= wn))
-        return R.myers_body(nw).valu_count()
+    if algo == B.ALGO_MYERS and wn <= 28:      # Peq planes resident (myers_global_asm_kernel): 10 VALU per word at every width
+        nw = wn if wn <= 8 or wn == 25 else next(n for n in list(range(10, 25, 2)) + [26, 28] if n >= wn)
+        return 10 * nw
     if algo == B.ALGO_MYERS and wn <= 32:      # 3-bit code planes (myers_global_planes_kernel)
         nw = next(n for n in range(26, 33, 2) if n >= wn)
         return R.myers_planes_body(nw).valu_count()

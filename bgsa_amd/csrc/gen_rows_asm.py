@@ -32,6 +32,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 import rows_ir as R  # noqa: E402
 
 MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25]  # Peq masks resident: 10 VALU per word (25 words = 253 VGPRs, the last width with two waves per SIMD)
+# resident Peq masks with 9 registers per word (rows_ir.myers_parked_body): 26 and 28 words (801..896 bp) fit 256 VGPRs at all,
+# 18 words (545..576 bp) drop from 183 to 165 VGPRs = three waves per SIMD instead of two
+MYERS_PARKED_NW = [18, 26, 28]
 MYERS_PEQ_BLOCK_NW = [12, 14, 16, 18, 20]  # column blocks with resident Peq planes (20 words: 238 VGPRs; 22 would need 256)
 MYERS_PAIR_NW = [1, 2]  # two rows per stream token: the 10-20 VALU row cannot hide the scalar dispatch
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word
@@ -915,7 +918,10 @@ def main() -> int:
              "                                               const uint32_t (&P)[5][G * NW],\n"
              "                                               const unsigned long long stream, const int n_windows);\n"]
     for nw in MYERS_NW:  # G = 1 only: two groups per wave measured slower (fewer waves per SIMD)
-        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_body(nw, 1), 2 * nw, nw))
+        if nw not in MYERS_PARKED_NW:
+            parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_body(nw, 1), 2 * nw, nw))
+    for nw in MYERS_PARKED_NW:  # 9 registers per word: HN parked in the VP register
+        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_parked_body(nw), 2 * nw, nw))
     parts.append("\n// Short subjects: the row is so short that the scalar dispatch bounds the loop, so a stream token\n"
                  "// carries two rows (bgsa_common.h: pair_stream_window).\n"
                  "// G = 2: two subject groups per wave — twice the vector work behind every dispatch, and these bodies are so\n"

@@ -30,6 +30,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "bgsa_common.h"
 
 namespace bgsa {
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 }
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
-constexpr int kPeqMaxWords = 25;  // default of myers_peq_max_words(): measured faster than the code planes up to here
+constexpr int kPeqMaxWords = 28;  // default of myers_peq_max_words(): measured faster than the code planes up to here
+constexpr int kSemiPeqMaxWords = 25;  // widest semi-global kernel with resident Peq planes (myers_semi_rows_asm)
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"
 
@@ -779,7 +782,7 @@ int myers_peq_max_words()
     static const int limit = [] {
         const char *e = getenv("BGSA_MYERS_PEQ_MAX_WORDS");
         const int v = e ? atoi(e) : kPeqMaxWords;
-        return (v >= 8 && v <= 25) ? v : kPeqMaxWords;
+        return (v >= 8 && v <= 28) ? v : kPeqMaxWords;
     }();
     return limit;
 }
@@ -798,7 +801,7 @@ int pick_semi_planes_nw(int word_num)
 int pick_peq_nw(int word_num)
 {
     if (word_num > myers_peq_max_words()) return -1;
-    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25})
+    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25, 26, 28})
         if (nw >= word_num) return nw;
     return -1;
 }
@@ -811,7 +814,7 @@ const char *myers_kernel_name(int word_num, int semi_global)
         int n_blocks = 0;
         if (myers_impl() != 0)
             snprintf(name, sizeof name, "myers_global_kernel<%d, 1, true>", nw);
-        else if (word_num <= myers_peq_max_words())
+        else if (word_num <= std::min(myers_peq_max_words(), kSemiPeqMaxWords))
             snprintf(name, sizeof name, "myers_semi_asm_kernel<%d>", pick_peq_nw(word_num));
         else if (word_num <= myers_semi_max_plain_words())
             snprintf(name, sizeof name, "myers_semi_planes_kernel<%d>", pick_semi_planes_nw(word_num));
@@ -844,7 +847,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
     if (semi_global && myers_impl() == 0) {
         // generated-asm kernels: resident Peq planes up to 24 words, code planes up to 32, column blocks (any length) beyond
-        if (word_num > myers_peq_max_words() && word_num <= myers_semi_max_plain_words()) {
+        if (word_num > std::min(myers_peq_max_words(), kSemiPeqMaxWords) && word_num <= myers_semi_max_plain_words()) {
             switch (pick_semi_planes_nw(word_num)) {
 #define BGSA_SEMI_PLANES_CASE(N)                                                                \
     case N:                                                                                     \
@@ -855,7 +858,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             default: break;
             }
         }
-        if (word_num <= myers_peq_max_words()) {
+        if (word_num <= std::min(myers_peq_max_words(), kSemiPeqMaxWords)) {
             switch (pick_peq_nw(word_num)) {
 #define BGSA_SEMI_CASE(N)                                                                       \
     case N:                                                                                     \
@@ -939,7 +942,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             BGSA_ASM_CASE(1) BGSA_ASM_CASE(2) BGSA_ASM_CASE(3) BGSA_ASM_CASE(4) BGSA_ASM_CASE(5)
             BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8) BGSA_ASM_CASE(10) BGSA_ASM_CASE(12)
             BGSA_ASM_CASE(14) BGSA_ASM_CASE(16) BGSA_ASM_CASE(18) BGSA_ASM_CASE(20) BGSA_ASM_CASE(22)
-            BGSA_ASM_CASE(24) BGSA_ASM_CASE(25)
+            BGSA_ASM_CASE(24) BGSA_ASM_CASE(25) BGSA_ASM_CASE(26) BGSA_ASM_CASE(28)
 #undef BGSA_ASM_CASE
         default: break;
         }

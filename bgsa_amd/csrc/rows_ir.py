@@ -362,6 +362,33 @@ def myers_body(nw: int, groups: int = 1) -> Body:
     return b
 
 
+def myers_parked_body(nw: int) -> Body:
+    """myers_body for 26..28 words: HN is parked in the VP register between the phases (as myers_planes_body does), so
+    a word needs 9 registers instead of 10 — 5 Peq masks, VP, VN, D0, HP — and 28 words (896 bp) still fit 256 VGPRs
+    with two waves per SIMD.  Same 10 instructions per word; state and masks as myers_body (one group)."""
+    b = Body()
+    P = lambda w: f"S{w * 2}"
+    M = lambda w: f"S{w * 2 + 1}"
+    E = lambda w: f"E{w}"
+    D = lambda w: f"d{w}"
+    HP = lambda w: f"hp{w}"
+    for w in range(nw):  # phase A
+        b.AND(D(w), P(w), E(w))
+        (b.ADD_CO if w == 0 else b.ADDC)(D(w), D(w), P(w))
+        b.BITOP3(D(w), D(w), P(w), M(w), lambda a, p, m: (a ^ p) | m)
+        b.OR(D(w), D(w), E(w))
+    b.SETC1()
+    for w in range(nw):  # phase C: HP chain; HN parks in the VP register
+        b.BITOP3(HP(w), D(w), P(w), M(w), lambda d, p, m: ~(d | p) | m)
+        b.AND(P(w), D(w), P(w))
+        b.ADDC(HP(w), HP(w), HP(w))
+    for w in range(nw):  # phase D: HN chain in place, then the new VP
+        (b.ADD_CO if w == 0 else b.ADDC)(P(w), P(w), P(w))
+        b.AND(M(w), D(w), HP(w))
+        b.BITOP3(P(w), D(w), HP(w), P(w), lambda d, hp, hn: ~(d | hp) | hn)
+    return b
+
+
 def myers_semi_body(nw: int) -> Body:
     """Semi-global Myers (generator -m 0 -s, MyersGenerator.java:56-223): the subject end to end inside the
     query — D[i][0] = 0 for every query row i, result = min over i of D[i][n].  The body is myers_body with

@@ -39,6 +39,24 @@ def test_myers_body_matches_oracle(oracle, qlen, slen):
         assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
 
 
+@pytest.mark.parametrize("qlen,slen,nw", [(300, 832, 26), (90, 896, 28), (1000, 801, 26), (64, 40, 2)])
+def test_myers_parked_body_matches_oracle(oracle, qlen, slen, nw):
+    """The 9-registers-per-word form of the Myers body (HN parked in the VP register): 26 and 28 words, 801..896 bp."""
+    q = oracle.gen_reads(5100 + qlen, 2, qlen)
+    s = oracle.gen_reads(5200 + slen, 24, slen)
+    m = min(qlen, slen)
+    s[:8, :m] = oracle.mutate(q[np.arange(8) % 2][:, :m], np.arange(8) * 3, 5300)
+    s[3, : slen // 3] = ord("N")
+    want = oracle.myers64(q, s)
+    body = R.myers_parked_body(nw)
+    peq = R.build_peq32(s, nw)
+    for i in range(q.shape[0]):
+        st = R.myers_init_state(nw, 1, s.shape[0])
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
+    assert body.valu_count() == 10 * nw and R.count_hazard_nops(body) == 0 and body.allocate_temps()[1] == 2 * nw
+
+
 @pytest.mark.parametrize("qlen,slen,nw", [(200, 60, 2), (150, 150, 5), (33, 97, 4), (1, 1, 1), (120, 64, 2), (300, 250, 8),
                                          (90, 257, 10), (150, 140, 5), (64, 32, 1), (40, 33, 2), (500, 300, 12)])
 def test_myers_semi_body_matches_the_dp(oracle, qlen, slen, nw):
