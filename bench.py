@@ -101,21 +101,49 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
     if algo == B.ALGO_BITPAL and wn <= 8:
         return R.bitpal_body(wn, R.BitpalScores(*scores) if scores else R.BITPAL_DEFAULT).valu_count()
     if algo == B.ALGO_BANDED:                  # per row that is actually run (early exit: fewer rows than nominal)
-        if k <= 15 and R.banded_phase_rows(k) and os.environ.get("BGSA_BANDED_IMPL", "")[:1] == "p":
+        impl = os.environ.get("BGSA_BANDED_IMPL", "")[:1]
+        if k <= 15 and R.banded_phase_rows(k) and impl == "p":
             return R.banded_phase_body().valu_count()     # the band held in place (A/B alternative, k <= 11)
+        if impl == "" and R.banded_cut_rows(k):
+            return R.banded_cut_body(1).valu_count()      # one-word windows (per group and row, whatever the groups per wave)
         return (R.banded_body() if k <= 15 else R.banded_body64()).valu_count()
     return None
 
 
-def pmc_values(config: int, tag: str = ""):
+KERNEL_SOURCES = {   # what defines the scoring kernel of an algorithm: its id stamps PMC passes and the bench line
+    B.ALGO_MYERS: ("myers_global.hip", "myers_rows_gen.inc", "long_kernels.hip", "bgsa_common.h"),
+    B.ALGO_BANDED: ("banded.hip", "banded_rows_gen.inc", "bgsa_common.h"),
+    B.ALGO_BITPAL: ("bitpal.hip", "bitpal_kernels.inl", "bitpal_rows_gen.inc", "long_kernels.hip", "bgsa_common.h"),
+}
+
+
+def kernel_source_id(algo: int) -> str:
+    """sha256 (16 hex digits) over the sources that define this algorithm's scoring kernels, in the tree the library was
+    built from.  A PMC pass is only comparable with a run of the SAME kernel: collect_profiles.py stamps every
+    profiles/*_pmc.csv with the id the profiled bench.py printed, pmc_values() refuses a file whose id differs."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[algo]:
+        h.update(name.encode() + b"\0" + (ROOT / "bgsa_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_values(config: int, tag: str = "", source_id: str | None = None):
     """Per-launch counter values of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*cfg<N><tag>_pmc.csv: separate --pmc runs of this same command, scripts/collect_profiles.py)."""
+    (profiles/*cfg<N><tag>_pmc.csv: separate --pmc runs of this same command, scripts/collect_profiles.py).
+    Returns (values, file name), or (None, reason) when there is no pass or the newest one was collected from another
+    kernel (its `_meta,kernel_source_id` row differs from source_id, or is missing)."""
     import csv
     import glob
     files = sorted(glob.glob(str(ROOT / "profiles" / f"*cfg{config}{tag}_pmc.csv")))
     if not files:
         return None, None
-    vals = {r["counter"]: float(r["value_per_launch"]) for r in csv.DictReader(open(files[-1]))}
+    rows = list(csv.DictReader(open(files[-1])))
+    meta = {r["counter"]: r["value_per_launch"] for r in rows if r.get("pass") == "_meta"}
+    if source_id is not None and meta.get("kernel_source_id") != source_id:
+        return None, (f"{Path(files[-1]).name} refused: collected from kernel source id {meta.get('kernel_source_id', 'unstamped')}, "
+                      f"this build is {source_id} — re-collect the PMC passes")
+    vals = {r["counter"]: float(r["value_per_launch"]) for r in rows if r.get("pass") != "_meta"}
     return vals, Path(files[-1]).name
 
 
@@ -131,18 +159,30 @@ def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> d
     sample = f"first {nq} queries x first {ns} subjects of the bench workload, {slen} bp"
     if O.have_reference(variant):
         try:
+            # the reference's guided OpenMP grid need not peak with every hardware thread busy: the best of three
+            # thread counts on the same sample, each by the reference's own cal timer
             t0 = time.time()
-            _, out = O.run_reference(variant, q_rows, s_rows, threads=threads, k=(k if algo == B.ALGO_BANDED else None),
-                                     want_scores=False, tmp_root="/dev/shm" if Path("/dev/shm").is_dir() else None)
-            rep = O.parse_gcups(out)
-            if rep.get("cal_seconds", 0) > 0:
+            tried, best = {}, None
+            for n_thr in sorted({threads, max(1, threads // 2), max(1, threads // 4)}, reverse=True):
+                _, out = O.run_reference(variant, q_rows, s_rows, threads=n_thr, k=(k if algo == B.ALGO_BANDED else None),
+                                         want_scores=False, tmp_root="/dev/shm" if Path("/dev/shm").is_dir() else None)
+                r = O.parse_gcups(out)
+                if r.get("cal_seconds", 0) > 0:
+                    tried[n_thr] = round(cells / r["cal_seconds"] / 1e9, 2)
+                    if best is None or r["cal_seconds"] < best[1]["cal_seconds"]:
+                        best = (n_thr, r)
+                if time.time() - t0 > 30:     # keep the default run bounded
+                    break
+            if best is not None:
+                threads, rep = best
                 base = {"value": cells / rep["cal_seconds"] / 1e9, "unit": "GCUPS", "cores": threads, "kind": "reference",
-                        "impl": f"reference {variant}/aligner -N {threads} (cal GCUPS, its own timer)",
+                        "impl": f"reference {variant}/aligner -N {threads} (cal GCUPS, its own timer; best of the thread counts tried)",
+                        "gcups_by_threads": tried,
                         "total_gcups": rep.get("total_gcups"), "sample": sample, "wall_s": round(time.time() - t0, 2)}
                 if algo == B.ALGO_MYERS:
                     # The reference's AVX2 Myers kernel is generator output that is not committed
                     # upstream (no JVM here): our own 8x32 AVX2 port of align_sse, for the record.
-                    _, secs = O.myers_avx2_timed(q_rows, s_rows[: ns // 8 * 8], threads=threads)
+                    _, secs = O.myers_avx2_timed(q_rows, s_rows[: ns // 8 * 8], threads=os.cpu_count() or 1)
                     base["avx2_port_gcups"] = round(float(nq) * (ns // 8 * 8) * qlen * slen / secs / 1e9, 2)
                 return base
         except Exception as e:  # fall through to the port
@@ -286,7 +326,10 @@ def main() -> int:
                     help="config 3, one GPU: other mixes timed after the main one ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total", action="store_true", help="skip the Total-GCUPS leg")
-    ap.add_argument("--cpu-sample", type=str, default="2000x100000", help="queries x subjects timed on the CPU")
+    ap.add_argument("--cpu-sample", type=str, default="1000x100000", help="queries x subjects timed on the CPU (once per thread count tried)")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="do not run the sustained-clock probe waves beside the timed kernels (set it under rocprofv3 --pmc, "
+                         "which may serialise kernels: the probes then delay the launch they are meant to observe)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -351,12 +394,37 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step_fn, steps, warmup):
+    # The sustained shader clock of the timed region (probe.hip): eight sleeping one-wave workgroups, one per XCD, read
+    # the shader-clock and the reference-clock counters beside the timed kernels.  Off under a profiler.
+    profiled = any(name.startswith(("ROCPROF", "ROCP_")) for name in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    use_probe = not args.no_clock_probe and not profiled
+    L = B.lib()
+
+    def probe_start(expected_s):
+        if not use_probe:
+            return False
+        return L.bgsa_hip_clock_probe_start(8, int(min(600000, max(2000, expected_s * 3e3 + 5000)))) == 0
+
+    def probe_stop():
+        mhz, xcc = (ctypes.c_double * 16)(), (ctypes.c_int * 16)()
+        n, secs = ctypes.c_int(0), ctypes.c_double(0)
+        if L.bgsa_hip_clock_probe_stop(mhz, xcc, 16, ctypes.byref(n), ctypes.byref(secs)) != 0 or n.value == 0:
+            return None
+        per = sorted((int(xcc[i]), round(float(mhz[i]), 1)) for i in range(n.value))
+        return {"sustained_mhz": round(float(np.mean([m for _, m in per])), 1), "nominal_mhz": 2400.0,
+                "per_probe_mhz": [m for _, m in per], "probe_xcc": [x for x, _ in per], "probe_seconds": round(secs.value, 3),
+                "method": "s_memtime / s_memrealtime deltas of sleeping one-wave workgroups (one per XCD, high-priority stream) "
+                          "that run beside the timed kernels from the opening fence to the closing one"}
+
+    def timed(step_fn, steps, warmup, probe=False):
         """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; wall time =
         max over ranks; kernel time = HIP events on the launch stream around each step."""
+        t_w = time.perf_counter()
         for _ in range(warmup):
             step_fn()
         fence()
+        per_step = (time.perf_counter() - t_w) / max(warmup, 1)
+        probing = probe and probe_start(per_step * steps)
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         t0 = time.perf_counter()
@@ -366,14 +434,28 @@ def main() -> int:
             ev1[i].record()
         fence()
         elapsed = time.perf_counter() - t0
+        clock_box[0] = probe_stop() if probing else None
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) / 1e3
 
-    elapsed, kernel_s = timed(lambda: aligner.score(0, nq, out=out), args.steps, args.warmup)
+    clock_box = [None]
+    elapsed, kernel_s = timed(lambda: aligner.score(0, nq, out=out), args.steps, args.warmup, probe=True)
+    clock = clock_box[0]
     aligner.check_faults()
+
+    # ---- evidence that N ranks on N devices ran: gathered through the process group itself ----------------------
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "device": props.name,
+          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "host": os.uname().nodename, "pid": os.getpid(), "kernel_ms": round(kernel_s * 1e3, 3),
+          "sustained_mhz": clock["sustained_mhz"] if clock else None}
+    ranks_info = [me]
+    if dist is not None:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
 
     # size-independent sanity on the full-size output
     checksum = int(out[:, :ns].to(torch.int64).sum().item()) if rank == 0 else 0
@@ -391,18 +473,28 @@ def main() -> int:
         pairs_per_launch = float(nq) * ns_pad
         bpp = algorithmic_bytes_per_pair(algo, length, wn)
         vpr = issued_valu_per_row(algo, wn, k, scores)
-        pmc, pmc_src = pmc_values(args.config, f"_{mix}" if mix else "") if not overridden else (None, None)
+        src_id = kernel_source_id(algo)
+        pmc, pmc_src = pmc_values(args.config, f"_{mix}" if mix else "", src_id) if not overridden else (None, None)
         wave_rows = float(nq) * (ns_pad // 64) * length          # nominal (query row, wave) pairs per launch
         issued = None
-        if pmc and "SQ_INSTS_VALU" in pmc:                       # measured: the counter of the same command
+        # the generator's own count (rows_ir.py instruction lists x rows x waves): exact when no wave exits early, an
+        # upper bound of the work when some do (banded mixes other than `survivors`) — always printed beside the counter
+        gen_ops = vpr * 64.0 * wave_rows / kernel_s if vpr else None
+        gen = ({"valu_per_row": vpr, "frac": round(gen_ops / VALU_PEAK_OPS, 4),
+                "exact": not (algo == B.ALGO_BANDED and mix != "survivors")} if vpr else None)
+        if pmc and "SQ_INSTS_VALU" in pmc:                       # measured: the counter of the same command, same kernel source
             ops = pmc["SQ_INSTS_VALU"] * 64.0 / kernel_s
             issued = {"source": f"SQ_INSTS_VALU, {pmc_src}", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
                       "valu_per_nominal_wave_row": round(pmc["SQ_INSTS_VALU"] / wave_rows, 3),
                       "achieved": round(ops / 1e12, 2), "unit": "Tops/s", "frac": round(ops / VALU_PEAK_OPS, 4)}
-        elif vpr and not (algo == B.ALGO_BANDED and mix != "survivors"):   # exact when no wave exits early
-            ops = vpr * 64.0 * wave_rows / kernel_s
+        elif gen and gen["exact"]:
             issued = {"source": "generator instruction lists (rows_ir.py) x rows x waves", "valu_per_row": vpr,
-                      "achieved": round(ops / 1e12, 2), "unit": "Tops/s", "frac": round(ops / VALU_PEAK_OPS, 4)}
+                      "achieved": round(gen_ops / 1e12, 2), "unit": "Tops/s", "frac": round(gen_ops / VALU_PEAK_OPS, 4)}
+        if issued is not None:
+            issued["generator_count"] = gen
+            issued["pmc_file"] = pmc_src
+            if clock:    # the same instructions against the clock this box really held: tells a slow box from a slower kernel
+                issued["frac_at_sustained_clock"] = round(issued["frac"] * 2400.0 / clock["sustained_mhz"], 4)
         traffic = None
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM (128-B requests tallied at 64 B); KB units
@@ -425,7 +517,11 @@ def main() -> int:
             "config": {"workload": cfg_name + (" [SIZE OVERRIDDEN]" if overridden else ""), "queries": nq,
                        "subjects_total": n_subjects_job, "subjects_this_rank": ns, "length_bp": length, "k": k,
                        "parallelism": f"subject-sharded x{world} ({scaling} scaling)",
-                       "kernel": aligner.kernel_name(), "word_num": wn},
+                       "kernel": aligner.kernel_name(), "word_num": wn, "kernel_source_id": src_id},
+            "clock": clock,
+            "ranks_seen": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["device_index"], r["pid"]) for r in ranks_info}),
+            "ranks": ranks_info,
+            "gather_ok": None,
             # The roofline that binds this path is the 32-bit integer VALU issue rate.  `achieved` /
             # `frac` are §8(d)'s figure: GCUPS x the REFERENCE's own ALU operations per cell.  It may exceed 1: the
             # kernels need fewer operations per cell than the reference counts (`ops_note`); `issued` is the
@@ -441,7 +537,7 @@ def main() -> int:
                 "ops_note": None,
                 "issued": issued,
                 "traffic": traffic,
-                "traffic_source": pmc_src if traffic else None,
+                "traffic_source": pmc_src if (traffic or pmc is None) else None,
                 "algorithmic_bytes": round(algorithmic_bytes),
                 "traffic_ratio": round(traffic / algorithmic_bytes, 2) if traffic else None,
                 "kernel_ms": round(kernel_s * 1e3, 3),
@@ -474,13 +570,19 @@ def main() -> int:
         limit = float(os.environ.get("BGSA_BENCH_GATHER_TIMEOUT", "180"))
 
         def give_up():
+            # The measured kernel-only line still goes out (its own copy, made under the lock: main() may be writing
+            # `result`), marked gather_ok = false — and every rank leaves with a NON-ZERO status: a leg that hung on
+            # the interconnect or the GPU is not a clean run, and a process that has touched the GPU is ended, not
+            # replaced.
             if rank != 0:
                 time.sleep(2.0)     # let rank 0 get its line out before peers start to disappear under it
             with print_lock:
                 if rank == 0 and not printed:
-                    result["gather"] = {"error": f"gather leg did not finish within {limit:.0f} s; value is the kernel-only figure"}
-                    print(json.dumps(result), flush=True)
-                os._exit(0)      # also ends a rank that printed its line and then hung in the closing barrier
+                    line = dict(result)
+                    line["gather"] = {"error": f"gather leg did not finish within {limit:.0f} s; value is the kernel-only figure"}
+                    line["gather_ok"] = False
+                    print(json.dumps(line), flush=True)
+                os._exit(3)      # also ends a rank that printed its line and then hung in the closing barrier
 
         watchdog = threading.Timer(limit, give_up)
         watchdog.daemon = True
@@ -526,7 +628,9 @@ def main() -> int:
             gather_info = {"error": repr(e)}
 
     if rank == 0 and gather_info:
-        result["gather"] = gather_info
+        with print_lock:
+            result["gather"] = gather_info
+            result["gather_ok"] = "error" not in gather_info
 
     # ---- config 3, one GPU: the other subject mixes (same kernel, same sizes) ---------------------------------
     if algo == B.ALGO_BANDED and world == 1 and args.banded_variants and not overridden:

@@ -357,6 +357,129 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
     }
 }
 
+// ---- one-word windows, one or two subject groups per wave (k <= 12): banded_cut_rows_asm_g{1,2} ------------------------
+// The default for k <= 12.  What round 3's microbenchmarks showed (scripts/ubench/gen_banded_mix.py,
+// profiles/r03_ubench_banded_mix.txt): a single half-rate-class instruction makes its whole row issue at ~4.2 cycles per
+// instruction instead of ~2.2 — the 12-instruction sliding row costs 52.8 cycles of vector issue with its v_alignbit and
+// 28.4 without — so the funnel shift leaves the row: per class the wave holds the 32 bits of the match string that start
+// at the last multiple of banded_cut_rows(k) rows (one v_alignbit per class and cut, in an event), and a row shifts that
+// word by `row mod cut` with v_lshrrev_b32, which is fast class.  With the vector side that short the loop's scalar side
+// (one scalar unit per CU) would bound it, so two subject groups share a wave and every dispatch, shift counter and event
+// (G = 2, the default; BGSA_BANDED_GROUPS=1 is the A/B): groups 2w and 2w+1, rows interleaved instruction by instruction.
+// The wave stops when all 128 lanes are past the limit; the regroup list takes (query, group, lane).
+template <int G>
+__global__ __launch_bounds__(256) void banded_cut_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
+    long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
+    unsigned *__restrict__ fault_word, const char *__restrict__ content, int ref_start, int len,
+    uint32_t push_row, uint32_t push_max, uint32_t cut_rows)
+{
+    __shared__ uint32_t s_regroup[kWavesPerBlock][kLanes];   // (query - q0) << 8 | group in wave << 6 | lane
+    uint32_t *regroup = s_regroup[threadIdx.x >> 6];
+    int n_regroup = 0;   // wave-uniform
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
+    if (group0 >= n_groups) return;
+    // an odd group count leaves the last wave's second half without a group: it runs the first one's again (loads only)
+    const bool has[2] = {true, G == 2 && group0 + 1 < n_groups};
+    const size_t group_words = static_cast<size_t>(kChars) * word_num * kLanes;
+    const uint32_t *g = mext + static_cast<size_t>(group0) * group_words;
+    const uint32_t gstride[2] = {0u, has[1] ? static_cast<uint32_t>(group_words * sizeof(uint32_t)) : 0u};
+
+    uint32_t first[G][kChars][2];   // words 0 and 1 stay across the tile's queries; word 2 is fetched by the row loop
+    unsigned long long base[kChars];
+#pragma unroll
+    for (int c = 0; c < kChars; c++) {
+        base[c] = uniform_u64(reinterpret_cast<unsigned long long>(g + static_cast<size_t>(c) * word_num * kLanes));
+#pragma unroll
+        for (int gg = 0; gg < G; gg++)
+#pragma unroll
+            for (int w = 0; w < 2; w++) first[gg][c][w] = g[gstride[gg] / 4 + (c * word_num + w) * kLanes + lane];
+    }
+    const int h = k;
+    const uint32_t band = static_cast<uint32_t>((1ull << (k + h + 1)) - 1ull);
+    const uint32_t limit = static_cast<uint32_t>(h + 1);   // err > k+h+1  <=>  errors since row k > h+1
+
+    const int q0 = blockIdx.y * q_tile;
+    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+    int8_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
+
+    for (int q = q0; q <= q1; q++) {
+        // the dense pass over the listed pairs (see banded_asm_kernel): one pair per lane, from row 0
+        if (n_regroup > kLanes - static_cast<int>(push_max) || (q == q1 && n_regroup > 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n_regroup) {
+                const uint32_t entry = regroup[lane];
+                const uint32_t gg = (entry >> 6) & 1u;
+                banded_finish_pair<uint32_t>(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num, k,
+                                             out + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes, ld);
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_regroup = 0;
+        }
+        if (q == q1) break;
+        uint32_t st[3 * G];
+#pragma unroll
+        for (int i = 0; i < 3 * G; i++) st[i] = 0u;
+        uint32_t M[G][kChars][4];
+        uint32_t voff[G];
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) {
+#pragma unroll
+            for (int c = 0; c < kChars; c++) {
+                M[gg][c][0] = first[gg][c][0];   // row 0: the first word itself
+                M[gg][c][1] = first[gg][c][0];
+                M[gg][c][2] = first[gg][c][1];
+            }
+            voff[gg] = static_cast<uint32_t>(lane * 4 + 2 * kLanes * 4) + gstride[gg];   // word 2 of this lane
+        }
+        const unsigned long long s =
+            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+        const int n_windows = __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2);
+        unsigned long long dead_mask[G];
+        int left, early;
+        if constexpr (G == 2)
+            banded_cut_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_max, dead_mask, left, early);
+        else
+            banded_cut_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_max, dead_mask, left, early);
+        note_stream_fault(fault_word, left);
+        if (early) {
+            // few lanes within the limit at a late test: they wait in the regroup list, the others are rejected here
+#pragma unroll
+            for (int gg = 0; gg < G; gg++) {
+                if (!has[gg]) continue;
+                const unsigned long long alive = ~dead_mask[gg];
+                if ((dead_mask[gg] >> lane) & 1ull)
+                    dst[static_cast<size_t>(q) * ld + gg * kLanes] = static_cast<int8_t>(HIP_MAX_ERROR);
+                else
+                    regroup[n_regroup + __popcll(alive & ((1ull << lane) - 1ull))] =
+                        (static_cast<uint32_t>(q - q0) << 8) | (static_cast<uint32_t>(gg) << 6) | lane;
+                n_regroup += __builtin_amdgcn_readfirstlane(static_cast<int>(__popcll(alive)));
+            }
+            continue;
+        }
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) {
+            if (!has[gg]) continue;
+            const bool dead = (dead_mask[gg] >> lane) & 1ull;
+            int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+            if (dead_mask[gg] != ~0ull) {
+                // :230-245 — walk the last row across the band, keep the minimum.
+                const uint32_t vp = st[3 * gg], vn = st[3 * gg + 1];
+                uint32_t err = static_cast<uint32_t>(k) + st[3 * gg + 2], best = err;
+                for (int i = 0; i <= h; i++) {
+                    err += (vp >> i) & 1u;
+                    err -= (vn >> i) & 1u;
+                    best = err < best ? err : best;
+                }
+                if (!dead) result = static_cast<int8_t>(best);
+            }
+            dst[static_cast<size_t>(q) * ld + gg * kLanes] = result;
+        }
+    }
+}
+
 // ---- regrouping of sparse survivors -------------------------------------------------------------------
 // The filter exists to reject: on realistic inputs a wave of 64 subjects holds at most a few pairs that
 // survive, and running all 64 lanes to the last row for them is what made sparse survivors expensive
@@ -507,9 +630,19 @@ int banded_impl()
 {
     static const int impl = [] {
         const char *e = getenv("BGSA_BANDED_IMPL");
-        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 's') ? 2 : ((e && e[0] == 'p') ? 3 : 0));
+        return (e && e[0] == 'c') ? 1 : ((e && e[0] == 's') ? 2 : ((e && e[0] == 'p') ? 3 : ((e && e[0] == 'a') ? 4 : 0)));
     }();
     return impl;
+}
+
+// Subject groups per wave of the one-word-window kernel (BGSA_BANDED_GROUPS, 1 or 2; default 2).
+int banded_groups()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_BANDED_GROUPS");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return v;
 }
 
 int launch_chunk(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len, int64_t read_count,
@@ -545,13 +678,19 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     const int64_t n_groups = read_count / kLanes;
     int q_tile = 32;
     while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
-    const int phase = banded_stream_phase(k);
-    if (int rc = launch_pack_banded(d_content, len, k, phase, ref_start, ref_end, d_workspace, stream)) return rc;
-    const int stride = banded_stream_layout(len, k, phase, nullptr, nullptr);
+    const int phase = banded_stream_phase(k), cut = banded_stream_cut(k);
+    const int G = cut > 0 ? banded_groups() : 1;
+    const int64_t n_waves = (n_groups + G - 1) / G;
+    if (G == 2) {   // half as many waves per query tile: keep the grid as fine
+        q_tile = 32;
+        while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_waves + 3) / 4) < 4096) q_tile >>= 1;
+    }
+    if (int rc = launch_pack_banded(d_content, len, k, phase, cut, ref_start, ref_end, d_workspace, stream)) return rc;
+    const int stride = banded_stream_layout(len, k, phase, cut, nullptr, nullptr);
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kBandedRefill, 40, stream, &fault)) return rc;
 
-    dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
+    dim3 grid(static_cast<unsigned>((n_waves + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
         set_error_text("banded: too many query tiles for one launch");
@@ -559,7 +698,17 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     }
     const uint32_t push_row = static_cast<uint32_t>(k + banded_push_row_offset());
     const uint32_t push_max = static_cast<uint32_t>(banded_push_max());
-    if (phase > 0)
+    if (cut > 0 && G == 2)
+        hipLaunchKernelGGL((banded_cut_kernel<2>), grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
+                           fault, d_content, ref_start, len, push_row, push_max, static_cast<uint32_t>(cut));
+    else if (cut > 0)
+        hipLaunchKernelGGL((banded_cut_kernel<1>), grid, dim3(256), 0, stream,
+                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
+                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
+                           fault, d_content, ref_start, len, push_row, push_max, static_cast<uint32_t>(cut));
+    else if (phase > 0)
         hipLaunchKernelGGL((banded_asm_kernel<false, true>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
@@ -608,12 +757,18 @@ int banded_stream_phase(int k)
     return (banded_impl() == 3 && k >= 1 && k <= 15) ? banded_phase_rows(k) : 0;
 }
 
+int banded_stream_cut(int k)
+{
+    return (banded_impl() == 0 && k >= 1) ? banded_cut_rows(k) : 0;
+}
+
 const char *banded_kernel_name(int word_num)
 {
     (void)word_num;
     if (banded_impl() == 1) return g_last_k <= 15 ? "banded_kernel<uint32_t>" : "banded_kernel<uint64_t>";
     if (banded_impl() == 2 && g_last_k <= 15) return "banded_chunk_kernel";
     if (banded_stream_phase(g_last_k) > 0) return "banded_asm_kernel<false, true>";
+    if (banded_stream_cut(g_last_k) > 0) return banded_groups() == 2 ? "banded_cut_kernel<2>" : "banded_cut_kernel<1>";
     return g_last_k <= 15 ? "banded_asm_kernel<false, false>" : "banded_asm_kernel<true, false>";
 }
 
@@ -634,7 +789,7 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
     if (banded_impl() == 2 && k <= 15)
         return launch_chunk(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                             d_workspace, stream);
-    if (banded_impl() != 1)   // 0 and 3: the threaded loop
+    if (banded_impl() != 1)   // 0, 3 and 4: the threaded loops
         return launch_asm(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                           d_workspace, stream);
     if (k <= 15)

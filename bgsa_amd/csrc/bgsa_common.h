@@ -124,6 +124,10 @@ __host__ __device__ inline int banded_phase_rows(int k)
     return rows >= kBandedPhaseMin ? rows : 0;
 }
 int banded_stream_phase(int k);   // banded.hip: the phase length the kernel launched for threshold k uses (0: sliding form)
+// Rows between two cuts of the one-word window form (rows_ir.py: banded_cut_body): the band's 2k + 1 bits, offset by up
+// to rows - 1 bits, must fit one 32-bit word.  0: no room worth it (k > 12) — those thresholds keep the funnel-shift row.
+__host__ __device__ inline int banded_cut_rows(int k) { return k <= 8 ? 16 : (k <= 12 ? 8 : 0); }
+int banded_stream_cut(int k);     // banded.hip: the cut length the kernel launched for threshold k uses (0: no cut events)
 inline size_t banded_stream_bound(int len)
 {
     const size_t events = static_cast<size_t>(len) / kBandedCheckRows + static_cast<size_t>(len) / 32 +
@@ -134,8 +138,9 @@ inline size_t banded_stream_bound(int len)
 }
 // EVENT bits: 1 = scoring starts (row k), 2 = next 32 rows (the match-string words move down), 4 = test the error
 // limit, 8 = latch the reject mask (the reference's last checkpoint), 16 = re-anchor the band (every `phase` rows;
-// phase = 0: the sliding form, no such event).
-__host__ __device__ inline int banded_stream_layout(int len, int k, int phase, const char *row, unsigned char *dst)
+// phase = 0: the sliding form, no such event), 32 = cut the next one-word window (every `cut` rows that do not also
+// advance the words; cut = 0: the funnel-shift row, no such event).
+__host__ __device__ inline int banded_stream_layout(int len, int k, int phase, int cut, const char *row, unsigned char *dst)
 {
     const int last = (len <= 64) ? len : ((len - k > 64) ? len - k : 64);
     int pos = 0, slot = 0, pending = 0;
@@ -164,7 +169,8 @@ __host__ __device__ inline int banded_stream_layout(int len, int k, int phase, c
     };
     // events due before row r starts / after `done` rows are complete
     auto before = [&](int r) {
-        return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0) | ((phase > 0 && r > 0 && r % phase == 0) ? 16 : 0);
+        return (r == k ? 1 : 0) | ((r > 0 && (r & 31) == 0) ? 2 : 0) | ((phase > 0 && r > 0 && r % phase == 0) ? 16 : 0) |
+               ((cut > 0 && r > 0 && r % cut == 0 && (r & 31) != 0) ? 32 : 0);
     };
     // Tests between checkpoints only decide how soon a wave may stop, never the result (the errors are monotone and
     // the reject mask is latched at `last`): none before a lane can be past the limit at all (more than k + 1 errors
@@ -230,7 +236,7 @@ __host__ __device__ inline int blocked_stream_layout(int len, const char *row, u
 int launch_pack_blocked(const char *d_content, int len, int ref_start, int ref_end, void *d_streams,
                         hipStream_t stream);
 
-int launch_pack_banded(const char *d_content, int len, int k, int phase, int ref_start, int ref_end, void *d_streams,
+int launch_pack_banded(const char *d_content, int len, int k, int phase, int cut, int ref_start, int ref_end, void *d_streams,
                        hipStream_t stream);
 
 int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int ref_len,

@@ -674,9 +674,9 @@ int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, 
 {
     if (!mapped_row || ref_len <= 0) return BGSA_HIP_EINVAL;
     if (algo == BGSA_ALGO_BANDED) {
-        const int phase = banded_stream_phase(k);
-        const int n = banded_stream_layout(ref_len, k, phase, nullptr, nullptr);
-        if (dst && cap >= n) banded_stream_layout(ref_len, k, phase, mapped_row, dst);
+        const int phase = banded_stream_phase(k), cut = banded_stream_cut(k);
+        const int n = banded_stream_layout(ref_len, k, phase, cut, nullptr, nullptr);
+        if (dst && cap >= n) banded_stream_layout(ref_len, k, phase, cut, mapped_row, dst);
         return n;
     }
     if (algo == BGSA_ALGO_MYERS && k == -2) {  // the two-rows-per-token stream (subjects <= 64 bp)
@@ -792,6 +792,7 @@ struct RowBatch {
     std::string queries;                  // the rows as uploaded (the caller's buffer may change under a launch in flight)
     std::vector<std::pair<RowBuf *, size_t>> staged;   // rows without an arena slot: copied after the wait, from `region`
     int region = 0;
+    size_t row_size = 0;                  // bytes per row of THIS launch (another resident bucket's rows may differ)
     ~RowBatch() { if (done) (void)hipEventDestroy(done); }
 };
 struct RowBuf {
@@ -886,6 +887,12 @@ static long row_arena_free(size_t size)
     std::lock_guard<std::mutex> lock(g_arena.mu);
     if (!g_arena.base || size > g_arena.slot_bytes) return -1;
     return static_cast<long>(g_arena.free_slots.size());
+}
+// Slots of the arena that are not on its free list: held by cached rows or by some thread's last row.
+static size_t row_arena_slots_out()
+{
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    return g_arena.n_slots - g_arena.free_slots.size();
 }
 static bool row_arena_too_small(size_t size)
 {
@@ -995,6 +1002,8 @@ static int seam_row_ahead()
     return n;
 }
 
+static bool row_batch_finish(const std::shared_ptr<RowBatch> &bt);   // below: wait + staged rows down
+
 static int seam_stream()  // g_seam held
 {
     int dev = 0;
@@ -1017,9 +1026,12 @@ static int seam_stream()  // g_seam held
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
+        // launches still in flight on the old device: bring their rows down — the staged ones too, which sit in the
+        // region buffers freed below — while that device is current
+        (void)hipSetDevice(g_host.device);
+        for (int i = 0; i < HostSeam::kRowRegions; i++) (void)row_batch_finish(g_host.region_owner[i]);
+        (void)hipSetDevice(dev);
         for (int i = 0; i < HostSeam::kRowRegions; i++) {
-            if (g_host.region_owner[i] && !g_host.region_owner[i]->waited && g_host.region_owner[i]->done)
-                (void)hipEventSynchronize(g_host.region_owner[i]->done);
             g_host.region_owner[i].reset();
             for (void **p : {&g_host.d_rowq_ring[i], &g_host.d_row_results[i]}) {
                 if (*p) (void)hipFree(*p);
@@ -1138,6 +1150,34 @@ static inline uint64_t now_ns()
 {
     return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(
         std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+
+// Waits for one row launch and brings down the rows that have no arena slot (through the page-locked staging buffer,
+// sized for the largest row seen).  Uses the batch's OWN row size and region: the batch may belong to another resident
+// bucket than the call that happens to wait for it.  g_seam held.  false: a HIP call failed.
+static bool row_batch_finish(const std::shared_ptr<RowBatch> &bt)
+{
+    if (!bt || bt->waited) return true;
+    const uint64_t t_ev = now_ns();
+    bool ok = !bt->done || hipEventSynchronize(bt->done) == hipSuccess;
+    g_event_ns.fetch_add(now_ns() - t_ev, std::memory_order_relaxed);
+    if (ok && !bt->staged.empty() && g_host.cap_stage < bt->row_size) {
+        if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
+        g_host.h_stage = nullptr;
+        g_host.cap_stage = 0;
+        ok = hipHostMalloc(&g_host.h_stage, bt->row_size, hipHostMallocPortable) == hipSuccess;
+        if (ok) g_host.cap_stage = bt->row_size;
+    }
+    for (size_t j = 0; ok && j < bt->staged.size(); j++) {
+        ok = g_host.d_row_results[bt->region] &&
+             hipMemcpyAsync(g_host.h_stage, static_cast<unsigned char *>(g_host.d_row_results[bt->region]) + bt->staged[j].second,
+                            bt->row_size, hipMemcpyDeviceToHost, g_host.stream) == hipSuccess &&
+             hipStreamSynchronize(g_host.stream) == hipSuccess;
+        if (ok) memcpy(bt->staged[j].first->p, g_host.h_stage, bt->row_size);
+    }
+    bt->staged.clear();
+    bt->waited = true;
+    return ok;
 }
 
 int bgsa_hip_row_cache_stats(uint64_t *hits, uint64_t *misses)
@@ -1369,18 +1409,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 };
                 auto wait_batch = [&](const std::shared_ptr<RowBatch> &bt) {
                     if (!bt || bt->waited) return;
-                    const uint64_t t_ev = now_ns();
-                    bool ok = hipEventSynchronize(bt->done) == hipSuccess;
-                    g_event_ns.fetch_add(now_ns() - t_ev, std::memory_order_relaxed);
-                    for (size_t j = 0; ok && j < bt->staged.size(); j++) {   // rows without an arena slot: through the staging buffer
-                        ok = hipMemcpyAsync(g_host.h_stage, static_cast<unsigned char *>(g_host.d_row_results[bt->region]) + bt->staged[j].second,
-                                            row_size, hipMemcpyDeviceToHost, g_host.stream) == hipSuccess &&
-                             hipStreamSynchronize(g_host.stream) == hipSuccess;
-                        if (ok) memcpy(bt->staged[j].first->p, g_host.h_stage, row_size);
-                    }
-                    bt->staged.clear();
-                    bt->waited = true;
-                    if (!ok) {
+                    if (!row_batch_finish(bt)) {
                         if (g_last_error.empty()) set_error_text("align_hip: scoring the query rows failed");
                         die("align_hip");
                     }
@@ -1394,6 +1423,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                     const uint64_t t_issue = now_ns();
                     auto bt = std::make_shared<RowBatch>();
                     bt->region = static_cast<int>(g_host.batch_seq++ % HostSeam::kRowRegions);
+                    bt->row_size = row_size;
                     const int reg = bt->region;
                     wait_batch(g_host.region_owner[reg]);     // the launch that used these device buffers before
                     bt->queries.reserve(static_cast<size_t>(n_rows) * stride);
@@ -1420,11 +1450,34 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                         g_host.row_bytes -= g_host.rows[oldest].scores->size;
                         g_host.rows.erase(g_host.rows.begin() + oldest);
                     }
-                    if (row_arena_too_small(row_size)) {      // a bigger bucket than the arena was carved for: start it over
-                        g_host.rows.clear();
-                        g_host.row_bytes = 0;
-                        last.scores.reset();
-                        (void)row_arena_recarve(row_size);
+                    if (row_arena_too_small(row_size)) {
+                        // A bigger bucket than the arena was carved for.  The arena can be carved anew only with every slot
+                        // back: the cache's own slot rows can be dropped, a slot that another host thread still holds in its
+                        // LastRow (an idle OpenMP worker keeps its last row across buckets) cannot.  So count first and touch
+                        // nothing unless the recarve will succeed; until then rows of this size take the heap / staged path.
+                        // Rows on the heap — among them the rows of a launch of THIS bucket still in flight, when this is the
+                        // read-ahead launch chained behind it — are never dropped here.
+                        size_t droppable = 0;
+                        bool own_in_cache = false;
+                        for (const CachedRow &c : g_host.rows) {
+                            if (c.scores->slot < 0) continue;
+                            long users = c.scores.use_count();
+                            if (last.scores == c.scores) { users--; own_in_cache = true; }
+                            if (users == 1) droppable++;
+                        }
+                        if (last.scores && last.scores->slot >= 0 && !own_in_cache && last.scores.use_count() == 1) droppable++;
+                        if (row_arena_slots_out() == droppable) {
+                            for (size_t j = 0; j < g_host.rows.size();) {
+                                if (g_host.rows[j].scores->slot >= 0) {
+                                    g_host.row_bytes -= g_host.rows[j].scores->size;
+                                    g_host.rows.erase(g_host.rows.begin() + j);
+                                } else {
+                                    j++;
+                                }
+                            }
+                            if (last.scores && last.scores->slot >= 0) last.scores.reset();
+                            (void)row_arena_recarve(row_size);
+                        }
                     }
                     hipStream_t s = g_host.stream;
                     bool ok = g_host.reserve(&g_host.d_rowq_ring[reg], &g_host.cap_rowq_ring[reg], bt->queries.size() + 16) == BGSA_HIP_OK &&
@@ -1445,14 +1498,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                             ok = hipMemcpyAsync(bufs[j]->p, static_cast<unsigned char *>(g_host.d_row_results[reg]) + static_cast<size_t>(j) * row_size,
                                                 row_size, hipMemcpyDeviceToHost, g_host.copy_stream) == hipSuccess;
                         } else {
-                            bt->staged.emplace_back(bufs[j].get(), static_cast<size_t>(j) * row_size);
-                            if (g_host.cap_stage < row_size) {
-                                if (g_host.h_stage) (void)hipHostFree(g_host.h_stage);
-                                g_host.h_stage = nullptr;
-                                g_host.cap_stage = 0;
-                                ok = hipHostMalloc(&g_host.h_stage, row_size, hipHostMallocPortable) == hipSuccess;
-                                if (ok) g_host.cap_stage = row_size;
-                            }
+                            bt->staged.emplace_back(bufs[j].get(), static_cast<size_t>(j) * row_size);   // row_batch_finish brings it down
                         }
                     }
                     // the device's fault word travels behind the rows (reading it with a blocking copy would wait for the
@@ -1473,7 +1519,9 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                         c.range_gen = r->gen;
                         c.params = params;
                         c.read_len = read_len;
-                        c.query.assign(first + static_cast<size_t>(j) * stride, first + static_cast<size_t>(j) * stride + ref_len);
+                        // the key is the bytes that were UPLOADED AND SCORED (the snapshot), never a second read of the caller's
+                        // buffer: a reader thread may have refilled the rows ahead of the one asked for in between
+                        c.query.assign(bt->queries.data() + static_cast<size_t>(j) * stride, static_cast<size_t>(ref_len));
                         c.scores = bufs[j];
                         c.stamp = ++g_host.clock;
                         g_host.row_bytes += row_size;

@@ -520,6 +520,279 @@ def gen_banded_function(wide: bool, phase: bool = False) -> str:
 """
 
 
+def gen_banded_cut_function(groups: int) -> str:
+    """Row loop of the one-word-window banded kernel (k <= 12; rows_ir.banded_cut_body), for one or two subject
+    groups per wave.  Same threaded-code skeleton, stream and events as gen_banded_function, plus EVENT bit 5 = cut.
+    Per group and class four registers: m0 = the cut word the rows shift (E), m1 / m2 = the 32-bit match-string words
+    the current 32 rows straddle (A, B), m3 = the next one, prefetched (C).  advance (bit 1, every 32 rows):
+    A <- B, B <- C, fetch C, E <- A; cut (bit 5, every `cutrows` rows in between): E <- ({B, A} >> rows since the
+    advance).  The row's shift count restarts at either.  With two groups the tests, the push decision and the early
+    exit look at both: the wave stops when all 128 lanes are past the limit."""
+    G = groups
+    body = R.banded_cut_body(G)
+    n_state = 3 * G
+    acc = [3 * g + 2 for g in range(G)]
+    slot_of, n_slots = body.allocate_temps()
+    S_CUT, S_SH, S_ARG, S_CUTROWS, S_THR, S_CNT = "s72", "s73", "s74", "s75", "s78", "s79"
+    S_DEAD = ["s[76:77]", "s[96:97]"]
+    S_ALIVE = ["s[90:91]", "s[98:99]"]
+    S_ANY, S_VCC1, S_CNT2 = "s[58:59]", "s[98:99]", "s57"   # (s100 / s101 are reserved by the compiler)
+    S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
+    S_CHUNK, S_PUSHROW, S_PUSHMAX, S_EARLY = "s92", "s93", "s94", "s95"
+    clobbers = ["s57", "s58", "s59"] + CLOBBERS[:-3] + [f"s{i}" for i in range(72, 100)] + ["vcc", "scc", "memory"]
+
+    def reg_for(c: int):
+        def reg(name: str) -> str:
+            if name.startswith("S"):
+                return f"%[s{name[1:]}]"
+            if name.startswith("E"):
+                return f"%[m0_{c}_{name[1:]}]"
+            if name == "$mask":
+                return "%[vmask]"
+            if name == "$sh":
+                return S_SH
+            if name == "$one":
+                return "1"
+            return f"%[t{slot_of[name]}]"
+        return reg
+
+    def disp() -> list[str]:
+        return [
+            f"s_and_b32 {S_C}, {S_WIN_LO}, 0x3f",
+            f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
+            f"s_mul_i32 {S_C}, {S_C}, (L_body1_%= - L_body0_%=)",
+            f"s_add_u32 {S_PC_LO}, {S_BASE_LO}, {S_C}",
+            f"s_addc_u32 {S_PC_HI}, {S_BASE_HI}, 0",
+            f"s_setpc_b64 {S_PC}",
+        ]
+
+    def pad(slot: int) -> str:
+        return f".fill ((L_body1_%= - L_body0_%=) - (L_end{slot}_%= - L_body{slot}_%=)) / 4, 4, 0xbf800000"
+
+    def test(tag: str) -> list[str]:
+        """err > limit on every lane of every group -> vcc (group 0), S_VCC1 (group 1); alive masks; scc = any alive."""
+        out = [f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc[0]}]"]
+        if G == 2:
+            out += [f"v_cmp_lt_u32_e64 {S_VCC1}, {S_THR}, %[s{acc[1]}]", "s_nop 1"]
+        return out
+
+    def alive() -> list[str]:
+        out = [f"s_andn2_b64 {S_ALIVE[0]}, exec, vcc"]
+        if G == 2:
+            # S_ALIVE[1] aliases S_VCC1: take the reject mask out first
+            out += [f"s_mov_b64 {S_ANY}, {S_VCC1}",
+                    f"s_andn2_b64 {S_ALIVE[1]}, exec, {S_ANY}",
+                    f"s_or_b64 {S_ANY}, {S_ALIVE[0]}, {S_ALIVE[1]}"]
+        return out
+
+    def latch_from_alive() -> list[str]:
+        """reject masks = the lanes that are not alive."""
+        return [f"s_andn2_b64 {S_DEAD[g]}, exec, {S_ALIVE[g]}" for g in range(G)]
+
+    def push_or(label_no: str) -> list[str]:
+        """Few survivors late enough: the wave stops here and hands them to the regroup list (banded.hip)."""
+        out = [
+            f"s_lshl_b32 {S_CNT}, {S_CHUNK}, 5",
+            f"s_add_u32 {S_CNT}, {S_CNT}, {S_CUT}",
+            f"s_add_u32 {S_CNT}, {S_CNT}, {S_SH}",
+            f"s_cmp_ge_u32 {S_CNT}, {S_PUSHROW}",
+            f"s_cbranch_scc0 {label_no}",
+            f"s_bcnt1_i32_b64 {S_CNT}, {S_ALIVE[0]}",
+        ]
+        if G == 2:
+            out += [f"s_bcnt1_i32_b64 {S_CNT2}, {S_ALIVE[1]}", f"s_add_u32 {S_CNT}, {S_CNT}, {S_CNT2}"]
+        out += [
+            f"s_cmp_le_u32 {S_CNT}, {S_PUSHMAX}",
+            f"s_cbranch_scc0 {label_no}",
+        ]
+        out += latch_from_alive()
+        out += [f"s_mov_b32 {S_EARLY}, 1", "s_branch L_done_%="]
+        return out
+
+    asm = [
+        f"s_mov_b64 {S_PTR}, %[qp]",
+        f"s_mov_b32 {S_LEFT}, %[nwin]",
+        f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+        f"s_mov_b32 {S_THR}, %[thr]",
+        f"s_mov_b32 {S_CUTROWS}, %[cutrows]",
+        f"s_mov_b32 {S_SH}, 0",
+        f"s_mov_b32 {S_CUT}, 0",
+        f"s_mov_b32 {S_CHUNK}, 0",
+        f"s_mov_b32 {S_EARLY}, 0",
+        f"s_mov_b32 {S_PUSHROW}, %[pushrow]",
+        f"s_mov_b32 {S_PUSHMAX}, %[pushmax]",
+    ]
+    asm += [f"s_mov_b64 {S_DEAD[g]}, 0" for g in range(G)]
+    asm += [f"s_mov_b64 {S_BASE[c]}, %[base{c}]" for c in range(5)]
+    # word 2 of every class is first needed after 32 rows: fetched here, awaited by the first advance event (ten registers
+    # less than keeping it across the queries of the tile)
+    for g in range(G):
+        asm += [f"global_load_dword %[m3_{c}_{g}], %[voff{g}], {S_BASE[c]}" for c in range(5)]
+    asm += [f"v_add_u32 %[voff{g}], 0x100, %[voff{g}]" for g in range(G)]
+    asm += [
+        f"s_getpc_b64 {S_PC}",
+        "L_anchor_%=:",
+        f"s_add_u32 {S_BASE_LO}, {S_PC_LO}, (L_body0_%= - L_anchor_%=)",
+        f"s_addc_u32 {S_BASE_HI}, {S_PC_HI}, 0",
+        "s_waitcnt lgkmcnt(0)",
+    ]
+    asm += disp()
+    def last_row_and_dispatch(c: int) -> list[str]:
+        """The token's last row with the next token's dispatch computed UNDER it: the five scalar instructions that turn
+        the next code into a jump target are a dependent chain (s_and -> s_mul -> s_add -> s_addc) followed by a taken
+        branch; behind the row they are ~40 cycles in which this wave issues nothing for the vector pipe, and with four
+        or five waves per SIMD that shows (two waves must be ready at any time to issue a vector instruction every other
+        cycle).  Woven between the row's vector instructions they cost issue slots only; the row's shift counter moves up
+        right behind the instructions that read it, so nothing but VALU sits between s_add and s_addc (SCC)."""
+        rows = body.emit_asm(reg_for(c), c)
+        head, rest = rows[:G], rows[G:]                      # the G window shifts read S_SH
+        out = head + [f"s_add_u32 {S_SH}, {S_SH}, 1"]
+        d = disp()
+        scalars, jump = d[:-1], d[-1]
+        gap = max(1, (len(rest) - 2) // (len(scalars) + 1))
+        k_next = 0
+        for i, ln in enumerate(rest):
+            out.append(ln)
+            if k_next < len(scalars) and i >= 1 and (i - 1) % gap == 0:
+                out.append(scalars[k_next])
+                k_next += 1
+        out += scalars[k_next:]
+        out.append(jump)
+        return out
+
+    for a in range(5):          # slots 0..24: two rows per token
+        for b2 in range(5):
+            asm.append(f"L_body{5 * a + b2}_%=:")
+            asm += body.emit_asm(reg_for(a), a)
+            asm.append(f"s_add_u32 {S_SH}, {S_SH}, 1")
+            asm += last_row_and_dispatch(b2)
+    for c in range(5):          # slots 25..29: one row
+        asm.append(f"L_body{25 + c}_%=:")
+        asm += last_row_and_dispatch(c)
+        asm.append(f"L_end{25 + c}_%=:")
+        asm.append(pad(25 + c))
+    asm.append("L_body30_%=:")  # END
+    asm.append("s_branch L_done_%=")
+    asm.append("L_end30_%=:")
+    asm.append(pad(30))
+    asm.append("L_body31_%=:")  # REFILL
+    asm += [
+        f"s_sub_u32 {S_LEFT}, {S_LEFT}, 1",
+        "s_cbranch_scc1 L_done_%=",
+        "s_waitcnt lgkmcnt(0)",
+        f"s_mov_b64 {S_WIN}, {S_NXT}",
+        f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 8",
+        f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+    ]
+    asm += disp()
+    asm.append("L_end31_%=:")
+    asm.append(pad(31))
+    for slot in range(32, 63):   # every value of the 6-bit dispatch mask that is no token: a fail slot
+        asm.append(f"L_body{slot}_%=:")
+        asm += fail_slot()
+        asm.append(f"L_end{slot}_%=:")
+        asm.append(pad(slot))
+    asm.append("L_body63_%=:")  # EVENT <arg>: the last slot, so it may be longer than the slot stride
+    asm += [
+        f"s_and_b32 {S_ARG}, {S_WIN_LO}, 0xff",
+        f"s_lshr_b64 {S_WIN}, {S_WIN}, 8",
+        f"s_cmp_eq_u32 {S_ARG}, 4",           # the plain test, by far the most frequent event: its own short path
+        "s_cbranch_scc0 L_ev_general_%=",
+    ]
+    asm += test("p") + alive()
+    asm += ["s_cbranch_scc0 L_ev_alldead_%="]
+    asm += push_or("L_ev_out_%=")
+    asm += ["L_ev_alldead_%=:"] + [f"s_mov_b64 {S_DEAD[g]}, exec" for g in range(G)] + ["s_branch L_done_%="]
+    asm += [
+        "L_ev_general_%=:",
+        f"s_bitcmp1_b32 {S_ARG}, 2",          # bit 2: test; bit 3: latch the reject masks (the reference's last checkpoint)
+        "s_cbranch_scc0 L_ev_reset_%=",
+    ]
+    asm += test("g") + alive()
+    asm += ["s_cbranch_scc0 L_ev_alldead_%=",
+            f"s_bitcmp1_b32 {S_ARG}, 3",
+            "s_cbranch_scc0 L_ev_nolatch_%="]
+    asm += latch_from_alive()
+    asm += ["L_ev_nolatch_%=:"]
+    asm += push_or("L_ev_reset_%=")
+    asm += [
+        "L_ev_reset_%=:",
+        f"s_bitcmp1_b32 {S_ARG}, 0",          # bit 0: scoring starts (row k)
+        "s_cbranch_scc0 L_ev_adv_%=",
+    ]
+    asm += [f"v_mov_b32 %[s{a}], 0" for a in acc]
+    asm += [
+        "L_ev_adv_%=:",
+        f"s_bitcmp1_b32 {S_ARG}, 1",          # bit 1: next 32 rows
+        "s_cbranch_scc0 L_ev_cut_%=",
+        "s_waitcnt vmcnt(0)",
+    ]
+    for g in range(G):
+        for c in range(5):
+            asm += [f"v_mov_b32 %[m1_{c}_{g}], %[m2_{c}_{g}]", f"v_mov_b32 %[m2_{c}_{g}], %[m3_{c}_{g}]"]
+    for g in range(G):
+        for c in range(5):
+            asm.append(f"global_load_dword %[m3_{c}_{g}], %[voff{g}], {S_BASE[c]}")
+    asm += [f"v_add_u32 %[voff{g}], 0x100, %[voff{g}]" for g in range(G)]
+    for g in range(G):
+        asm += [f"v_mov_b32 %[m0_{c}_{g}], %[m1_{c}_{g}]" for c in range(5)]
+    asm += [
+        f"s_mov_b32 {S_SH}, 0",
+        f"s_mov_b32 {S_CUT}, 0",
+        f"s_add_u32 {S_CHUNK}, {S_CHUNK}, 1",
+        "L_ev_cut_%=:",
+        f"s_bitcmp1_b32 {S_ARG}, 5",          # bit 5: the next one-word window of every class
+        "s_cbranch_scc0 L_ev_out_%=",
+        f"s_add_u32 {S_CUT}, {S_CUT}, {S_CUTROWS}",
+        f"s_mov_b32 {S_SH}, 0",
+    ]
+    for g in range(G):
+        asm += [f"v_alignbit_b32 %[m0_{c}_{g}], %[m2_{c}_{g}], %[m1_{c}_{g}], {S_CUT}" for c in range(5)]
+    asm += ["L_ev_out_%=:"]
+    asm += disp()
+    asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    asm += [f"s_mov_b64 %[dead{g}], {S_DEAD[g]}" for g in range(G)]
+    asm.append(f"s_mov_b32 %[early], {S_EARLY}")
+
+    text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += [f'[m{w}_{c}_{g}] "{"=&v" if w == 3 else "+v"}"(M[{g}][{c}][{w}])' for g in range(G) for c in range(5) for w in range(4)]
+    outs += [f'[voff{g}] "+v"(voff[{g}])' for g in range(G)]
+    outs += [f'[dead{g}] "=s"(dead[{g}])' for g in range(G)]
+    outs += ['[left] "=s"(left)', '[early] "=s"(early)']
+    outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
+    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[vmask] "v"(band_mask)', '[thr] "s"(limit)', '[cutrows] "s"(cut_rows)',
+           '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
+    ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
+    clob = ", ".join(f'"{x}"' for x in clobbers)
+    return f"""
+// One-word-window banded rows, {G} subject group{'s' if G > 1 else ''} per wave: {body.valu_count()} VALU per row, all fast class
+// ({sum(op.kind in ('alignbit',) for op in body.ops)} funnel shifts in the row; the cut event holds them), {n_slots} temporaries.
+// state[3g..3g+2] = {{VP, VN, errors since row k}} of group g; M[g][c] = {{cut word, word i, word i + 1, word i + 2 (prefetch
+// target, fetched by the loop itself: no input)}} of class c's offset match string; voff[g] = byte offset of word i + 2 relative
+// to base[c] (group 1: the group stride included); dead[g] = reject mask of group g (lanes whose error count passed `limit` at the last
+// checkpoint, or all lanes if the wave stopped with every lane of every group past it); left / early as banded_rows_asm32
+// (early: the lanes NOT in dead[] go to the regroup list).
+__device__ __forceinline__ void banded_cut_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][4], uint32_t (&voff)[{G}],
+                                                       const unsigned long long (&base)[5],
+                                                       const unsigned long long stream, const int n_windows,
+                                                       const uint32_t band_mask, const uint32_t cut_rows,
+                                                       const uint32_t limit, const uint32_t push_row,
+                                                       const uint32_t push_max, unsigned long long (&dead)[{G}],
+                                                       int &left, int &early)
+{{
+    uint32_t tmp[{max(n_slots, 1)}];
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+}}
+"""
+
+
 def gen_banded_chunk_function() -> str:
     """Banded row loop for the 32-bit band (k <= 15) WITHOUT a per-row jump: straight-line code for 32 rows, the
     query character selecting the match words through an LDS ADDRESS instead of a branch.
@@ -979,7 +1252,7 @@ def main() -> int:
     (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))
     # ---- banded -------------------------------------------------------------------------------
     (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(False, phase=True) + gen_banded_function(True) +
-                                              gen_banded_chunk_function())
+                                              gen_banded_chunk_function() + gen_banded_cut_function(1) + gen_banded_cut_function(2))
     return 0
 
 

@@ -209,23 +209,23 @@ int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, i
 
 // One thread per query writes its banded stream (a few hundred bytes; the layout is sequential).
 __global__ __launch_bounds__(64) void pack_banded_kernel(const char *__restrict__ content,
-                                                         unsigned char *__restrict__ streams, int len, int k, int phase,
+                                                         unsigned char *__restrict__ streams, int len, int k, int phase, int cut,
                                                          int ref_start, int n_queries, int stride)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_queries) return;
-    banded_stream_layout(len, k, phase, content + static_cast<size_t>(ref_start + q) * (len + 1),
+    banded_stream_layout(len, k, phase, cut, content + static_cast<size_t>(ref_start + q) * (len + 1),
                          streams + static_cast<size_t>(q) * stride);
 }
 
-int launch_pack_banded(const char *d_content, int len, int k, int phase, int ref_start, int ref_end, void *d_streams,
+int launch_pack_banded(const char *d_content, int len, int k, int phase, int cut, int ref_start, int ref_end, void *d_streams,
                        hipStream_t stream)
 {
     const int nq = ref_end - ref_start;
     if (nq <= 0) return BGSA_HIP_OK;
-    const int stride = banded_stream_layout(len, k, phase, nullptr, nullptr);
+    const int stride = banded_stream_layout(len, k, phase, cut, nullptr, nullptr);
     hipLaunchKernelGGL(pack_banded_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, d_content,
-                       static_cast<unsigned char *>(d_streams), len, k, phase, ref_start, nq, stride);
+                       static_cast<unsigned char *>(d_streams), len, k, phase, cut, ref_start, nq, stride);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

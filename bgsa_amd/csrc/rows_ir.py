@@ -82,6 +82,7 @@ class Body:
     def ADD(self, d, a, b): return self._emit("add", d, a, b)          # d = a + b, no carry
     def LSHR1(self, d, a): return self._emit("lshr1", d, a)            # d = a >> 1 (slow class)
     def ALIGNBIT(self, d, hi, lo, sh): return self._emit("alignbit", d, hi, lo, sh)  # ({hi,lo} >> sh)[31:0], sh scalar
+    def LSHRS(self, d, a, sh): return self._emit("lshrs", d, a, sh)   # d = a >> sh, sh scalar (VOP2 v_lshrrev_b32: fast class)
 
     def MATCH3(self, d, b0, b1, b2, wild=False):
         """d = columns whose 3-bit character code (b2 b1 b0) equals the row's class (0..4 = A C G T
@@ -170,6 +171,7 @@ class Body:
             elif k == "mov": wr(op.dst, s[0])
             elif k == "add": wr(op.dst, (s[0].astype(np.uint64) + s[1].astype(np.uint64)) & np.uint64(0xFFFFFFFF))
             elif k == "lshr1": wr(op.dst, s[0] >> np.uint32(1))
+            elif k == "lshrs": wr(op.dst, s[0] >> s[1].astype(np.uint32))
             elif k == "alignbit":
                 pair = (s[0].astype(np.uint64) << np.uint64(32)) | s[1].astype(np.uint64)
                 wr(op.dst, (pair >> s[2].astype(np.uint64)) & np.uint64(0xFFFFFFFF))
@@ -227,6 +229,7 @@ class Body:
             elif k == "add": lines.append(f"v_add_u32 {d}, {r[0]}, {r[1]}")
             elif k == "lshr1": lines.append(f"v_lshrrev_b32 {d}, 1, {r[0]}")
             elif k == "alignbit": lines.append(f"v_alignbit_b32 {d}, {r[0]}, {r[1]}, {r[2]}")
+            elif k == "lshrs": lines.append(f"v_lshrrev_b32 {d}, {r[1]}, {r[0]}")
             elif k == "bitop3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm:02x}")
             elif k == "match3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm[cls]:02x}")
             elif k == "add_co": lines.append(f"v_add_co_u32 {d}, vcc, {r[0]}, {r[1]}")
@@ -710,6 +713,50 @@ def banded_body() -> Body:
     return b
 
 
+def banded_cut_rows(k: int) -> int:
+    """Rows between two cuts of the one-word window form (bgsa_common.h: banded_cut_rows): the band's 2k + 1 bits,
+    offset by up to rows - 1 bits, must fit one 32-bit word.  0: no room worth it (k > 12) — the funnel-shift row."""
+    return 16 if k <= 8 else (8 if k <= 12 else 0)
+
+
+def banded_cut_body(groups: int = 1) -> Body:
+    """The sliding row WITHOUT its funnel shift (k <= 12), for one or two subject groups per wave.
+
+    scripts/ubench/gen_banded_mix.py on MI355X (profiles/r03_ubench_banded_mix.txt): ONE half-rate-class instruction
+    in a row makes the whole row issue at ~4.2 cycles per instruction instead of ~2.2 — banded_body's row costs 52.8
+    cycles of vector issue with its v_alignbit and 28.4 with a v_mov in its place — and v_alignbit is in that class
+    with any kind of shift operand, while v_lshrrev_b32 is not (by an immediate, a VGPR, or — among other
+    instructions — an SGPR).  So the window of a row must come out of ONE register: the kernel keeps, per class, the
+    32 bits of the match string that start at the last multiple of banded_cut_rows(k) rows ("cut": one v_alignbit
+    per class every 16 rows for k <= 8, every 8 for k <= 12, in an event) and the row shifts that word right by
+    `row mod cut` — at most cut - 1, which leaves the band's 2k + 1 bits inside the word.  Every instruction of the
+    row is then fast class.  E<g> = group g's cut word of the row's class; state S<3g..3g+2> = VP, VN, errors.
+    groups = 2: two subject groups share the wave (and the stream's scalar work); their rows are interleaved
+    instruction by instruction, two independent dependency chains."""
+    per = []
+    for g in range(groups):
+        b = Body()
+        t = lambda n, g=g: f"{n}{g}"
+        S = lambda i, g=g: f"S{3 * g + i}"
+        b.LSHRS(t("w"), f"E{g}", "$sh")
+        b.BITOP3(t("x"), t("w"), "$mask", S(1), lambda w, m, vn: (w & m) | vn)
+        b.AND(t("t"), t("x"), S(0))
+        b.ADD(t("t"), t("t"), S(0))
+        b.BITOP3(t("d"), t("t"), S(0), t("x"), lambda t_, vp, x: (t_ ^ vp) | x)
+        b.BITOP3(t("hp"), t("d"), S(0), S(1), lambda d, vp, vn: ~(d | vp) | vn)
+        b.AND(t("hn"), t("d"), S(0))
+        b.LSHR1(t("x2"), t("d"))
+        b.AND(S(1), t("x2"), t("hp"))
+        b.BITOP3(S(0), t("hp"), t("x2"), t("hn"), lambda hp, x2, hn: ~(hp | x2) | hn)
+        b.BITOP3(t("e"), t("d"), "$one", "$one", lambda d, one, _o: ~d & one)
+        b.ADD(S(2), S(2), t("e"))
+        per.append(b.ops)
+    out = Body()
+    for ops in zip(*per):
+        out.ops.extend(ops)
+    return out
+
+
 def banded_body64() -> Body:
     """64-bit band (16 <= k <= 31) as register pairs.  State: S0/S1 = VP lo/hi, S2/S3 = VN lo/hi,
     S4 = errors since row k.  E0..E2 = three consecutive 32-bit words of the class match string;
@@ -792,12 +839,13 @@ BANDED_CHECK_ROWS = 8   # bgsa_common.h: kBandedCheckRows
 BANDED_LATE_ROWS = 48   # bgsa_common.h: kBandedLateRows
 
 
-def banded_tokens(length: int, k: int, word_bits: int = 32, phase: int = 0):
+def banded_tokens(length: int, k: int, word_bits: int = 32, phase: int = 0, cut: int = 0):
     """The per-query token sequence of the banded stream, query characters as ('row', r):
     ('event', bits) with bits 1 = reset the error count (row k), 2 = advance the match-string
     words (every word_bits rows), 4 = test err > limit on all lanes, 8 = latch the reject mask
     (the reference's last checkpoint), 16 = re-anchor the band (every `phase` rows; 0, the default: the sliding
-    form, no such event).  Mirrors banded_stream_layout() in bgsa_common.h."""
+    form, no such event), 32 = cut the next one-word window (every `cut` rows that do not also advance the words;
+    0: the funnel-shift row, no such event).  Mirrors banded_stream_layout() in bgsa_common.h."""
     last = banded_last_check(length, k)
     out, pending = [], 0
     for r in range(length):
@@ -807,6 +855,8 @@ def banded_tokens(length: int, k: int, word_bits: int = 32, phase: int = 0):
             pending |= 2
         if phase and r > 0 and r % phase == 0:
             pending |= 16
+        if cut and r > 0 and r % cut == 0 and r % word_bits != 0:
+            pending |= 32
         if pending:
             out.append(("event", pending))
             pending = 0
@@ -826,7 +876,7 @@ def banded_tokens(length: int, k: int, word_bits: int = 32, phase: int = 0):
 BANDED_SINGLE, BANDED_END, BANDED_REFILL, BANDED_EVENT = 25, 30, 31, 63
 
 
-def banded_stream_bytes(length: int, k: int, codes, phase: int = 0) -> list:
+def banded_stream_bytes(length: int, k: int, codes, phase: int = 0, cut: int = 0) -> list:
     """The packed banded stream, byte for byte as bgsa_common.h: banded_stream_layout() writes it:
     banded_tokens() with two consecutive rows folded into one token (5*a + b) wherever no event sits
     between them, one-row tokens 25 + c otherwise, EVENT = {63, bits}, 7 payload bytes + REFILL per
@@ -849,7 +899,7 @@ def banded_stream_bytes(length: int, k: int, codes, phase: int = 0) -> list:
         put(BANDED_EVENT)
         put(bits)
 
-    toks = banded_tokens(length, k, phase=phase)
+    toks = banded_tokens(length, k, phase=phase, cut=cut)
     i = 0
     while i < len(toks):
         kind, val = toks[i]
@@ -869,8 +919,78 @@ def banded_stream_bytes(length: int, k: int, codes, phase: int = 0) -> list:
     return out
 
 
+def _banded_simulate_cut(subjects: np.ndarray, query: np.ndarray, k: int, cut: int, groups: int) -> np.ndarray:
+    """banded_cut_kernel<G> on the CPU: banded_cut_body(groups) — the subjects split into `groups` halves that share
+    the token stream —, the cut / advance events as the generated loop runs them (E = ({B, A} >> cut offset) after an
+    advance or a cut; the row shifts E by the rows since), the final band walk."""
+    n, length = subjects.shape
+    assert n % groups == 0
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, c in zip(b"ACGTN", range(5)):
+        code[ch] = c
+    mapped = code[subjects]
+    nwords = (length + 31) // 32 + 3
+    mext = np.zeros((5, nwords, n), dtype=np.uint32)
+    for p in range(length):
+        i = p + k + 1
+        for c in range(5):
+            mext[c, i // 32] |= (mapped[:, p] == c).astype(np.uint32) << np.uint32(i % 32)
+    h = k
+    band_mask = np.uint32((1 << (2 * k + 1)) - 1)
+    body = banded_cut_body(groups)
+    per = n // groups
+    sl = [slice(g * per, (g + 1) * per) for g in range(groups)]
+    st = [np.zeros(per, dtype=np.uint32) for _ in range(3 * groups)]
+    dead = np.zeros(n, dtype=bool)
+    wi, sh, off = 0, 0, 0
+    E = [[mext[c, 0, sl[g]].copy() for c in range(5)] for g in range(groups)]   # row 0: the first word itself
+
+    def recut():
+        for g in range(groups):
+            for c in range(5):
+                pair = (mext[c, wi + 1, sl[g]].astype(np.uint64) << np.uint64(32)) | mext[c, wi, sl[g]].astype(np.uint64)
+                E[g][c] = ((pair >> np.uint64(off)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+    qcode = code[query]
+    stopped = False
+    for kind, val in banded_tokens(length, k, phase=0, cut=cut):
+        if kind == "event":
+            if val & 4:
+                over = np.concatenate([st[3 * g + 2] > np.uint32(h + 1) for g in range(groups)])
+                if val & 8:
+                    dead = over.copy()
+                if over.all():
+                    stopped = True
+                    break
+            if val & 1:
+                for g in range(groups):
+                    st[3 * g + 2] = np.zeros(per, dtype=np.uint32)
+            if val & 2:
+                wi, sh, off = wi + 1, 0, 0
+                recut()
+            if val & 32:
+                off, sh = off + cut, 0
+                recut()
+        else:
+            c = int(qcode[val])
+            assert sh < cut and sh + 2 * k + 1 <= 32
+            body.simulate(st, [E[g][c] for g in range(groups)], scalars={"$sh": sh, "$mask": band_mask, "$one": 1})
+            sh += 1
+    if stopped:
+        return np.full(n, 127, dtype=np.int8)
+    out = np.empty(n, dtype=np.int8)
+    for g in range(groups):
+        err = st[3 * g + 2].astype(np.int64) + k
+        best = err.copy()
+        for i in range(h + 1):
+            err = err + ((st[3 * g] >> np.uint32(i)) & 1) - ((st[3 * g + 1] >> np.uint32(i)) & 1)
+            best = np.minimum(best, err)
+        out[sl[g]] = np.where(dead[sl[g]], 127, best).astype(np.int8)
+    return out
+
+
 def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool | None = None,
-                    phase: int = 0) -> np.ndarray:
+                    phase: int = 0, cut: int = 0, groups: int = 1) -> np.ndarray:
     """Whole banded pipeline on the CPU with the shipped row body: Mext preprocess, token
     stream, events, final band walk.  Returns int8 results like the kernel.  wide = the 64-bit
     band body (register pairs), the default for k > 15."""
@@ -880,6 +1000,8 @@ def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool 
         return _banded_simulate64(subjects, query, k)
     if phase:
         return _banded_simulate_phase(subjects, query, k, phase)
+    if cut:
+        return _banded_simulate_cut(subjects, query, k, cut, groups)
     n, length = subjects.shape
     code = np.zeros(256, dtype=np.uint8)
     for ch, c in zip(b"ACGTN", range(5)):

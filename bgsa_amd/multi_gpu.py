@@ -146,6 +146,7 @@ class ScoreGatherStream:
         else:   # a peer only needs a contiguous copy of its tile when the caller's view is strided
             self.staging = [None] * self.depth
         self.pending = [[] for _ in range(self.depth)]   # outstanding transfers per slot
+        self.held = [None] * self.depth                  # the caller's tile (and its contiguous copy) of the slot's block
         self.n_submitted = 0
         self.blocks_checked = 0
         self.last = None    # root: (slot, rows) of the most recent block
@@ -154,6 +155,7 @@ class ScoreGatherStream:
         for w in self.pending[slot]:
             w.wait()
         self.pending[slot] = []
+        self.held[slot] = None                       # the transfers that read the tile are done
         for seg, host in self.host_parts.pop(slot, []):
             seg.copy_(host.view(seg.dtype).view(seg.shape), non_blocking=False)
         if slot in self.unflushed:
@@ -170,8 +172,12 @@ class ScoreGatherStream:
 
     def submit(self, tile):
         """tile: this rank's [rows <= block_rows, count_rank] scores of one query block (device tensor, may
-        be a strided view).  Returns at once; the tile must stay untouched until drain() or until
-        `depth` further blocks have been submitted."""
+        be a strided view).  Returns at once.  The side stream reads the tile later than this call returns, so the
+        stream keeps it alive itself: a reference per slot until the slot's transfers are done, and
+        `record_stream` so that the caching allocator does not hand the block to the compute stream's next
+        kernel meanwhile — callers may pass temporaries (run_streamed does).  A caller that REUSES one buffer
+        for every block must still leave it untouched until drain() or until `depth` further blocks have been
+        submitted."""
         torch = self.torch
         rows = int(tile.shape[0])
         if rows > self.block_rows or int(tile.shape[1]) != self.counts[self.rank]:
@@ -186,7 +192,9 @@ class ScoreGatherStream:
         with ctx:
             if self.cuda:
                 self.side.wait_event(ready)          # the kernel that wrote the tile
+                tile.record_stream(self.side)
             self._wait_slot(slot)                    # the slot's previous block has left / arrived
+            self.held[slot] = [tile]
             ops = []
             if self.rank == 0:
                 buf = self.blocks[slot]
@@ -210,6 +218,7 @@ class ScoreGatherStream:
                     src = self.staging[slot][:rows]
                     src.copy_(tile, non_blocking=True)
                 flat = src.reshape(-1).view(torch.uint8)
+                self.held[slot].append(flat)
                 ops.append(self.dist.P2POp(self.dist.isend, flat.cpu() if self.via_host else flat, 0))
             if ops:
                 self.pending[slot] = self.dist.batch_isend_irecv(ops)
@@ -300,31 +309,6 @@ class ShardedAligner:
         self.dist.broadcast(buf, src=0)
         return buf.cpu().numpy()
 
-    def gather_scores(self, local, shards: list[Shard], layout: str = "row_major"):
-        """Gather [nq, count_r] tiles on rank 0.
-
-        layout "row_major": one [nq, n_subjects] tensor (subjects in file order);
-        layout "device_blocks": the reference's result.txt order for one read bucket — device 0's
-        [nq, count_0] block, then device 1's, ... (cal_mic.c:535-536) — as a flat tensor.
-        """
-        torch = self.torch
-        if self.dist is None:
-            return local if layout == "row_major" else local.reshape(-1)
-        nq = local.shape[0]
-        widest = max(s.count for s in shards)
-        pad = torch.zeros((nq, widest), dtype=local.dtype, device=local.device)
-        pad[:, : local.shape[1]] = local
-        # scores travel as raw bytes: gloo has no int16/int8 gather, RCCL does not care
-        raw = pad.view(torch.uint8)
-        tiles = [torch.empty_like(raw) for _ in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(raw, tiles, dst=0)
-        if self.rank != 0:
-            return None
-        parts = [t.view(local.dtype)[:, : s.count] for t, s in zip(tiles, shards)]
-        if layout == "row_major":
-            return torch.cat(parts, dim=1)
-        return torch.cat([p.reshape(-1) for p in parts])
-
     def run_streamed(self, queries, subjects_all, block_rows: int = 100, layout: str = "device_blocks", ratios=None,
                      score_block=None):
         """The bucket scored block by block (block_rows queries, the reference's REF_BUCKET_COUNT) with the
@@ -359,4 +343,10 @@ class ShardedAligner:
         local = self.score_fn(q, subjects_all[mine.start: mine.start + mine.count])
         if not gather:
             return local, shards
-        return self.gather_scores(local, shards, layout), shards
+        # the gather is the streamed one with a single block of all the queries: every peer's tile goes straight
+        # into its segment of root's buffer (nothing padded to the widest shard, nothing staged `world` times)
+        gs = ScoreGatherStream(self.dist, local.device, [s.count for s in shards], local.dtype, max(int(local.shape[0]), 1), layout)
+        gs.submit(local)
+        gs.drain()
+        out = gs.last_block()
+        return (out.clone() if out is not None else None), shards

@@ -286,6 +286,14 @@ int bgsa_hip_cal_align_score_ex(const bgsa_hip_params_t *params, const char *d_c
 int bgsa_hip_stream_faults(int clear);
 int bgsa_hip_debug_inject_stream_fault(int kind);
 
+/* The sustained shader clock while other launches run (bench.py's `clock` object): n_probes one-wave workgroups
+ * (8 cover the 8 XCDs) are started on a high-priority stream of the library's own and sleep, reading the shader-clock
+ * and the constant reference-clock counters, until bgsa_hip_clock_probe_stop() or until max_ms have passed — they
+ * never outlive that bound.  stop() returns per probe the clock in MHz over its lifetime and the XCD it ran on, and
+ * the longest probe lifetime in seconds.  Measurement only: nothing in the scoring path depends on it. */
+int bgsa_hip_clock_probe_start(int n_probes, unsigned max_ms);
+int bgsa_hip_clock_probe_stop(double *mhz, int *xcc, int cap, int *n_out, double *seconds);
+
 /* Introspection (host only, no GPU): the packed code stream the kernels walk for one mapped query
  * row, 8-byte windows of 7 tokens + REFILL.  Myers / BitPAl: codes 0..4 = row of that character
  * class, 5 = END, 6 = REFILL; for BGSA_ALGO_MYERS, k = -1 selects the stream of the column-block

@@ -34,6 +34,8 @@ def clobbered(func: str) -> set:
         regs |= {80, 81}
     if "banded_asm_kernel" in func:
         regs |= set(range(72, 96))
+    if "banded_cut_kernel" in func:
+        regs |= set(range(72, 100)) | {57, 58, 59}
     if "banded_chunk_kernel" in func:
         regs = set(range(60, 94))
     return regs

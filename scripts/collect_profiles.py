@@ -58,6 +58,22 @@ for key, dirs in groups.items():
                 note = "KB"
             rows.append((Path(d).name, ctr, f"{tot / len(disp):.0f}", kern, note))
     if rows:
+        # provenance: the kernel source id the PROFILED bench.py printed in its line (config.kernel_source_id); bench.py's
+        # pmc_values() refuses the file when the library it runs was built from other kernel sources
+        ids = set()
+        for d in dirs:
+            log = Path(str(d) + ".log")
+            if log.exists():
+                for ln in log.read_text(errors="replace").splitlines():
+                    if ln.startswith("{") and "kernel_source_id" in ln:
+                        try:
+                            ids.add(json.loads(ln)["config"]["kernel_source_id"])
+                        except Exception:
+                            pass
+        if len(ids) == 1:
+            rows.insert(0, ("_meta", "kernel_source_id", ids.pop(), rows[0][3], "sha256[:16] of the kernel's sources (bench.py: kernel_source_id)"))
+        elif ids:
+            print(f"{key}: the passes disagree on the kernel source id {sorted(ids)} — not stamped", file=sys.stderr)
         with open(dst / f"{prefix}_{key}_pmc.csv", "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["pass", "counter", "value_per_launch", "kernel", "note"])

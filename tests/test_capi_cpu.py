@@ -142,9 +142,10 @@ def test_banded_query_stream_matches_the_token_model(L, length, k):
     buf = np.full(n, 0xEE, dtype=np.uint8)
     assert L.bgsa_hip_query_stream(B.ALGO_BANDED, row.ctypes.data, length, k, buf.ctypes.data, n) == n
     # byte for byte the Python model of the layout ...
-    assert buf.tolist() == R.banded_stream_bytes(length, k, row)
+    cut = R.banded_cut_rows(k)      # the default form for k <= 12 carries cut events (BGSA_BANDED_IMPL unset)
+    assert buf.tolist() == R.banded_stream_bytes(length, k, row, cut=cut)
     # ... which decodes to exactly the row / event sequence the simulator executes
-    want = [("row", int(row[v])) if kind == "row" else ("event", v) for kind, v in R.banded_tokens(length, k)]
+    want = [("row", int(row[v])) if kind == "row" else ("event", v) for kind, v in R.banded_tokens(length, k, cut=cut)]
     assert _decode_banded_stream(buf) == want
     assert n % 8 == 0 and (buf[-8:] == 30).all()
     assert (buf < 25).sum() >= length // 2 - 2 * (length // 16 + 3)      # most rows travel in pairs

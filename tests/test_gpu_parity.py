@@ -690,6 +690,74 @@ def test_align_hip_row_cache_variants(env):
     assert launches == (70 if env.get("BGSA_HIP_ROW_AHEAD") == "1" else 2)      # without read-ahead one launch per query; else query 0, then query 1 with its followers
 
 
+_TWO_BUCKETS_SCRIPT = r"""
+import sys, ctypes, threading, numpy as np
+sys.path.insert(0, sys.argv[1])
+import bgsa_amd as B, oracle as O
+L = B.lib()
+length, wn = 150, 5
+L.bgsa_hip_select_algorithm(B.ALGO_MYERS); L.init_mapping_table()
+table = np.ctypeslib.as_array((ctypes.c_uint32 * 128).in_dll(L, "mapping_table"))
+def bucket(seed, groups):
+    s, _ = B.pad_rows(O.gen_reads(seed, 64 * groups, length))
+    sbuf = B.rows_to_buffer(s)
+    seq = B.SeqT(len=length, size=sbuf.size, count=s.shape[0], extra_size=0, extra_count=0, content=sbuf.ctypes.data)
+    peq = np.zeros(B.group_words(B.ALGO_MYERS, wn) * groups, dtype=np.uint32)
+    L.hip_handle_reads(ctypes.byref(seq), peq.ctypes.data, wn, 0, s.shape[0])
+    return s, peq, (sbuf, seq)
+nq = 70
+q = O.gen_reads(111, nq, length)
+qb = B.rows_to_buffer(q); keep = qb == 10; qm = table[qb].astype(np.uint8); qm[keep] = 10
+block = L.malloc_mem(1 << 16)
+buf = np.ctypeslib.as_array(ctypes.cast(block, ctypes.POINTER(ctypes.c_uint8)), shape=(1 << 16,)); buf[:] = 0; buf[: qm.size] = qm
+small, peq_small, keep_small = bucket(112, 3)      # rows of 384 bytes: the arena is carved for them (4 KiB slots)
+big, peq_big, keep_big = bucket(113, 40)           # rows of 5,120 bytes: wider than the arena's slots
+want_small, want_big = O.myers64(q, small), O.myers64(q, big)
+def ask(peq, n, i, out):
+    L.align_hip(block + i * (length + 1), peq.ctypes.data, length, length, wn, n // 64, 0, out.ctypes.data, None)
+# a worker of the host's thread team scores one row of the small bucket and then idles: its thread-local last row
+# keeps an arena slot for as long as the thread lives
+scored, leave, errors = threading.Event(), threading.Event(), []
+def idle_worker():
+    out = np.zeros(small.shape[0], dtype=np.int16)
+    ask(peq_small, small.shape[0], 3, out)
+    if not np.array_equal(out, want_small[3]): errors.append("worker row")
+    scored.set(); leave.wait()
+    ask(peq_small, small.shape[0], 3, out)          # its last row must still be intact after the big bucket went by
+    if not np.array_equal(out, want_small[3]): errors.append("worker row afterwards")
+t = threading.Thread(target=idle_worker); t.start(); scored.wait()
+# the main thread walks the bigger bucket (launches chained ahead of the calls), with rows of the small one in between
+out_big, out_small = np.zeros((nq, big.shape[0]), dtype=np.int16), np.zeros((nq, small.shape[0]), dtype=np.int16)
+for i in range(nq):
+    ask(peq_big, big.shape[0], i, out_big[i])
+    if i % 9 == 4:
+        ask(peq_small, small.shape[0], i, out_small[i])
+        assert np.array_equal(out_small[i], want_small[i]), ("small", i)
+assert np.array_equal(out_big, want_big)
+leave.set(); t.join()
+assert not errors, errors
+L.bgsa_hip_bucket_release(None); L.free_mem(block)
+print("two buckets ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"BGSA_HIP_ROW_ARENA": "0"}, {"BGSA_HIP_ROW_AHEAD": "7"}])
+def test_align_hip_bigger_bucket_while_another_thread_holds_a_row(env):
+    """A host thread that scored a row of a small bucket stays alive (an idle OpenMP worker keeps its thread-local last
+    row, and with it a slot of the row arena) while the main thread walks a bucket whose rows are wider than the arena's
+    slots, interleaved with rows of the small one.  The arena cannot be carved anew then: the rows must take the heap /
+    staged path with each launch's OWN row size, the rows of the launch in flight must survive the read-ahead launch
+    chained behind it, and nobody's row may be lost (round 2's code emptied the cache on every miss and died with 'the
+    row just scored is not in the cache').  Child process: the arena is carved once per process."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(B.__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, "-c", _TWO_BUCKETS_SCRIPT, str(root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "two buckets ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_align_hip_from_many_threads(oracle):
     """Eight host threads hammer align_hip with random (query, chunk) requests on one bucket, as an OpenMP team with a
     dynamic schedule would: every chunk must come back right whatever the interleaving of misses, launches kept ahead

@@ -65,7 +65,7 @@ def test_two_ranks_hip_compute_and_streamed_gather(tmp_path, oracle, algo, layou
     assert np.array_equal(got, np.concatenate(parts))
 
 
-def _bench_two_ranks(extra_env, extra_args=()):
+def _bench_two_ranks(extra_env, extra_args=(), want_rc=0):
     """bench.py exactly as the driver starts it for N = 2, except that both ranks share this box's one card and the
     collectives go through gloo (BGSA_BENCH_SAME_GPU / BGSA_BENCH_BACKEND: a rehearsal of the code path, not a
     measurement)."""
@@ -76,7 +76,7 @@ def _bench_two_ranks(extra_env, extra_args=()):
            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--nq", "300", "--ns", "64000", *extra_args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert (p.returncode == 0) if want_rc == 0 else (p.returncode != 0), p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
@@ -94,11 +94,16 @@ def test_bench_line_for_two_ranks(config):
     assert "error" not in g, g
     assert g["root_blocks_checked"] >= 3 and g["gcups_with_gather"] > 0
     assert "cpu_baseline" not in r and "total_gcups" not in r       # rank 0 at N = 1 only
+    # the line proves that two ranks ran: gathered through the process group, one entry per rank with its own kernel time
+    assert r["gather_ok"] is True
+    assert [x["rank"] for x in r["ranks"]] == [0, 1] and r["ranks_seen"] == 2
+    assert all(x["kernel_ms"] > 0 and x["device"] for x in r["ranks"]) and r["ranks"][0]["pid"] != r["ranks"][1]["pid"]
+    assert r["config"]["kernel_source_id"] and len(r["config"]["kernel_source_id"]) == 16
 
 
 def test_bench_line_survives_a_gather_that_never_finishes():
-    """An interconnect problem is a hang, not an exception: the watchdog prints the kernel-only line and every rank
-    leaves with exit code 0."""
-    r = _bench_two_ranks({"BGSA_BENCH_GATHER_TIMEOUT": "0.001"}, ("--config", "2"))
+    """An interconnect problem is a hang, not an exception: the watchdog prints the kernel-only line, marked
+    gather_ok = false, and every rank leaves with a NON-ZERO exit code — a hung leg is not a clean run."""
+    r = _bench_two_ranks({"BGSA_BENCH_GATHER_TIMEOUT": "0.001"}, ("--config", "2"), want_rc=3)
     assert r["n_gpus"] == 2 and r["value"] > 0
-    assert "did not finish" in r["gather"]["error"]
+    assert "did not finish" in r["gather"]["error"] and r["gather_ok"] is False

@@ -216,6 +216,28 @@ def test_banded_band_held_in_place_matches_oracle(oracle, length, k):
     assert len(ev) == (length - 1) // phase
 
 
+@pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (64, 8), (65, 8), (200, 8), (150, 9), (33, 1), (100, 12), (31, 3), (481, 8), (150, 11)])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_banded_one_word_windows_match_oracle(oracle, length, k, groups):
+    """The default form for k <= 12 (banded_cut_kernel<G>): the row shifts ONE register — the 32 bits of the match string
+    cut at the last multiple of banded_cut_rows(k) rows — so it holds no half-rate instruction; cut / advance events
+    between the rows; one or two subject groups behind every token.  Same results as the oracle."""
+    cut = R.banded_cut_rows(k)
+    assert cut == (16 if k <= 8 else 8) and cut - 1 + 2 * k + 1 <= 32
+    q = oracle.gen_reads(4500 + length + k, 3, length)
+    s = oracle.gen_reads(4600 + length + k, 96, length)
+    s[:48] = oracle.mutate(q[np.arange(48) % 3], np.arange(48) % (2 * k + 6), length + k)
+    want = oracle.banded64(q, s, k)
+    for i in range(q.shape[0]):
+        assert np.array_equal(R.banded_simulate(s, q[i], k, cut=cut, groups=groups), want[i])
+    body = R.banded_cut_body(groups)
+    assert body.valu_count() == 12 * groups and not any(op.kind == "alignbit" for op in body.ops)
+    assert R.banded_cut_rows(13) == 0
+    # the stream: a cut event in front of every cut-th row that does not start a new 32-row chunk
+    ev = [v for kind, v in R.banded_tokens(length, k, cut=cut) if kind == "event" and v & 32]
+    assert len(ev) == (length - 1) // cut - (length - 1) // 32
+
+
 def test_emitted_asm_respects_the_vcc_hazard():
     for body in (R.myers_body(5), R.myers_body(3, groups=2), R.bitpal_body(5), R.myers_planes_body(12), R.myers_block_body(12)):
         lines = body.emit_asm(lambda name: name)
