@@ -446,12 +446,24 @@ def main() -> int:
     clock = clock_box[0]
     aligner.check_faults()
 
+    # ---- HBM traffic of one launch, modelled from the launch geometry: every query tile re-reads the rank's Peq / Mext
+    # blocks once, every score is written once, every stream read once per subject workgroup column (L2-resident: not
+    # counted).  Where a PMC pass exists (N = 1) the counters check the model; per rank at N > 1 the model is what
+    # there is (config 5: does the ratio grow when eight GPUs' slices shrink? — it depends on the tile, not the slice).
+    q_tile_used = int(L.bgsa_hip_last_query_tile())
+    traffic_model = None
+    if q_tile_used > 0 and "blocked" not in aligner.kernel_name():
+        peq_bytes = B.group_words(algo, aligner.wn, k) * 4 * (ns_pad // 64)
+        model_bytes = -(-nq // q_tile_used) * peq_bytes + float(nq) * ns_pad * out.element_size()
+        traffic_model = {"query_tile": q_tile_used, "bytes": round(model_bytes),
+                         "ratio_to_algorithmic": round(model_bytes / (float(nq) * ns_pad * algorithmic_bytes_per_pair(algo, length, aligner.wn)), 2)}
+
     # ---- evidence that N ranks on N devices ran: gathered through the process group itself ----------------------
     props = torch.cuda.get_device_properties(dev)
     me = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "device": props.name,
           "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
           "host": os.uname().nodename, "pid": os.getpid(), "kernel_ms": round(kernel_s * 1e3, 3),
-          "sustained_mhz": clock["sustained_mhz"] if clock else None}
+          "sustained_mhz": clock["sustained_mhz"] if clock else None, "subjects": ns, "traffic_model": traffic_model}
     ranks_info = [me]
     if dist is not None:
         ranks_info = [None] * world
@@ -540,6 +552,7 @@ def main() -> int:
                 "traffic_source": pmc_src if (traffic or pmc is None) else None,
                 "algorithmic_bytes": round(algorithmic_bytes),
                 "traffic_ratio": round(traffic / algorithmic_bytes, 2) if traffic else None,
+                "traffic_model": traffic_model,
                 "kernel_ms": round(kernel_s * 1e3, 3),
                 "kernel_gcups": round(kernel_gcups, 1),
                 "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; kernel time from HIP events on the launch stream; "

@@ -25,6 +25,7 @@
 // SURVEY.md §8(a) A5) — anything else is refused loudly.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "bgsa_common.h"
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
     unsigned *__restrict__ fault_word, const char *__restrict__ content, int ref_start, int len,
-    uint32_t push_row, uint32_t push_max, uint32_t cut_rows)
+    uint32_t push_row, uint32_t push_row_solid, uint32_t solid_limit, uint32_t push_max, uint32_t cut_rows)
 {
     __shared__ uint32_t s_regroup[kWavesPerBlock][kLanes];   // (query - q0) << 8 | group in wave << 6 | lane
     uint32_t *regroup = s_regroup[threadIdx.x >> 6];
@@ -440,9 +441,9 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
         unsigned long long dead_mask[G];
         int left, early;
         if constexpr (G == 2)
-            banded_cut_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_max, dead_mask, left, early);
+            banded_cut_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         else
-            banded_cut_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_max, dead_mask, left, early);
+            banded_cut_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         note_stream_fault(fault_word, left);
         if (early) {
             // few lanes within the limit at a late test: they wait in the regroup list, the others are rejected here
@@ -608,6 +609,24 @@ int banded_push_max()
     }();
     return v;
 }
+int banded_push_solid_offset()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_BANDED_PUSH_SOLID");
+        const int x = e ? atoi(e) : 40;
+        return x >= 0 ? x : 40;
+    }();
+    return v;
+}
+int banded_push_solid_margin()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_BANDED_SOLID_MARGIN");
+        const int x = e ? atoi(e) : 2;
+        return x >= 0 ? x : 2;
+    }();
+    return v;
+}
 int banded_push_row_offset()
 {
     static const int v = [] {
@@ -652,6 +671,7 @@ int launch_chunk(const char *d_content, const uint32_t *d_peq, int8_t *d_results
     const int64_t n_groups = read_count / kLanes;
     int q_tile = 32;
     while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
@@ -690,6 +710,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kBandedRefill, 40, stream, &fault)) return rc;
 
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_waves + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
@@ -698,16 +719,21 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     }
     const uint32_t push_row = static_cast<uint32_t>(k + banded_push_row_offset());
     const uint32_t push_max = static_cast<uint32_t>(banded_push_max());
+    // one-word-window kernels: already from this row on if an alive lane is a solid survivor (gen_rows_asm.py: push_or)
+    const uint32_t push_row_solid = std::min(push_row, static_cast<uint32_t>(k + banded_push_solid_offset()));
+    // a solid survivor: at most this many errors since row k (the limit is k + 1; default: two below it)
+    const int margin = banded_push_solid_margin();
+    const uint32_t solid_limit = static_cast<uint32_t>(k + 1 > margin ? k + 1 - margin : 0);
     if (cut > 0 && G == 2)
         hipLaunchKernelGGL((banded_cut_kernel<2>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
-                           fault, d_content, ref_start, len, push_row, push_max, static_cast<uint32_t>(cut));
+                           fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut));
     else if (cut > 0)
         hipLaunchKernelGGL((banded_cut_kernel<1>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
-                           fault, d_content, ref_start, len, push_row, push_max, static_cast<uint32_t>(cut));
+                           fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut));
     else if (phase > 0)
         hipLaunchKernelGGL((banded_asm_kernel<false, true>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
@@ -735,6 +761,7 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
     const int64_t n_groups = read_count / kLanes;
     int q_tile = 32;
     while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {

@@ -249,6 +249,7 @@ struct BitpalSet {
     int match, mismatch, gap;
     int planes;      // bit-planes of state per 32 subject columns
     int chains;      // inter-word carry chains per row (carry words per 32 rows of a column block)
+    int carry_words; // > 0: packed-carry column blocks — this many carry words per direction and ROW (rows_ir.py: make_blocked_packed)
     int max_plain;   // widest subject, in words, whose state stays in registers; beyond: column blocks
     int valu_per_word;
     int (*launch)(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
@@ -324,6 +325,10 @@ size_t long_state_bytes(int algo, int word_num);
 int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                 int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, void *d_state,
                 hipStream_t stream);
+
+// Queries per Peq / Mext load of this thread's last scoring launch (bgsa_hip_last_query_tile: bench.py models the
+// launch's HBM traffic from it — tiles x block bytes + scores — where no PMC pass is at hand, e.g. per rank at N > 1).
+void note_query_tile(int q_tile);
 
 int launch_preprocess(int algo, const char *d_rows, int64_t avail_bytes, int len,
                       int64_t read_count, int word_num, int k, uint32_t *d_peq, hipStream_t stream);

@@ -170,6 +170,74 @@ __global__ __launch_bounds__(256) void bitpal_blocked_kernel(
     }
 }
 
+// The same for score sets with so many carry chains that a register pair per chain does not fit (kBitpalPackedBlocks;
+// rows_ir.py: make_blocked_packed): the carries of one row are bits of kBitpalCarryWords words per direction, and the
+// row loop exchanges them with the neighbouring blocks every row — carry buffer [row][word][64 lanes] per wave, one row
+// more than the query has (the loop fetches one row ahead), zeroed per query: every chain of block 0 starts at carry-in 0.
+template <int NW, bool SEMI>
+__global__ __launch_bounds__(256) void bitpal_packed_blocked_kernel(
+    const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq, int16_t *__restrict__ out,
+    uint32_t *__restrict__ carry_all, int ref_len, int read_len, long long ld, int n_groups, int word_num,
+    int n_queries, int q_tile, int stream_stride_bytes, int n_blocks, unsigned long long *task_counter,
+    unsigned *__restrict__ fault_word)
+{
+    constexpr int semi = SEMI;
+    constexpr int CW = kBitpalCarryWords;
+    constexpr int NS = kBitpalPlanes * NW;
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int wave = threadIdx.x >> 6;
+    const int n_rows = ref_len + 1;
+    uint32_t *carry = carry_all + (static_cast<size_t>(blockIdx.x) * kWavesPerBlock + wave) * n_rows * CW * kLanes;
+    const unsigned long long carry_base = uniform_u64(reinterpret_cast<unsigned long long>(carry));
+    const int q_tiles = (n_queries + q_tile - 1) / q_tile;
+    const long long n_tasks = static_cast<long long>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock) * q_tiles;
+    dephase_persistent_workgroup();
+
+    for (long long task = next_blocked_task(task_counter); task < n_tasks; task = next_blocked_task(task_counter)) {
+        const int group = __builtin_amdgcn_readfirstlane(static_cast<int>(task / q_tiles) * kWavesPerBlock + wave);
+        const int tile = static_cast<int>(task % q_tiles);
+        if (group >= n_groups) continue;
+        const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+        const int q0 = tile * q_tile;
+        const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+        for (int q = q0; q < q1; q++) {
+            for (int i = 0; i < n_rows * CW; i++) carry[i * kLanes + lane] = 0u;
+            const unsigned long long s =
+                reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+            int score = semi ? kBitpalGap * ref_len : kBitpalGap * (ref_len + read_len);
+            int run = score;
+            for (int blk = 0; blk < n_blocks; blk++) {
+                uint32_t P[kChars][NW];
+#pragma unroll
+                for (int c = 0; c < kChars; c++)
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const int gw = blk * NW + w;
+                        const int gwc = gw < word_num ? gw : word_num - 1;
+                        P[c][w] = g[(c * word_num + gwc) * kLanes] & (gw < word_num ? ~0u : 0u);
+                    }
+                uint32_t st[NS + 2 * CW], next_in[CW];
+#pragma unroll
+                for (int i = 0; i < NS; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);
+#pragma unroll
+                for (int j = 0; j < CW; j++) {
+                    st[NS + j] = 0u;
+                    st[NS + CW + j] = 0u;
+                    next_in[j] = carry[j * kLanes + lane];   // row 0
+                }
+                uint32_t voff = static_cast<uint32_t>(lane * 4);
+                note_stream_fault(fault_word, bitpal_packed_block_rows_asm<NW>(st, P, next_in, voff, carry_base, uniform_u64(s),
+                                                                               __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
+                if (semi)
+                    bitpal_last_row_max<NW>(st, blk * NW, read_len, run, score);
+                else
+                    score += bitpal_column_sum<NW>(st, blk * NW, read_len);
+            }
+            out[static_cast<size_t>(q) * ld + static_cast<size_t>(group) * kLanes + lane] = static_cast<int16_t>(score);
+        }
+    }
+}
+
 namespace {
 
 // Narrowest instantiated block width that covers word_num words with the fewest blocks.
@@ -201,10 +269,63 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     hipLaunchKernelGGL(kernel, dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
-                       blocked_q_tile(nq, read_count / kLanes),
+                       (note_query_tile(blocked_q_tile(nq, read_count / kLanes)), blocked_q_tile(nq, read_count / kLanes)),
                        stride, n_blocks, counter, fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
+}
+
+// Bytes of the packed-carry buffers (capi.hip sizes the workspace with the same formula: BitpalSet::carry_words).
+inline size_t packed_carry_bytes(int ref_len)
+{
+    return static_cast<size_t>(ref_len + 1) * kBitpalCarryWords * kLanes * sizeof(uint32_t) * kWavesPerBlock * blocked_workgroups();
+}
+
+template <int NW>
+int launch_packed_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
+                          int64_t read_count, int ref_start, int ref_end, int word_num, int n_blocks, void *d_workspace,
+                          hipStream_t stream, int semi)
+{
+    const int nq = ref_end - ref_start;
+    const int stride = static_cast<int>(stream_stride(ref_len));
+    // the same workspace split as launch_blocked (capi.hip sizes the stream part for the longer CARRY-token stream)
+    const size_t stream_bytes = (static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * nq + 255) & ~static_cast<size_t>(255);
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    uint32_t *carry = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_workspace) + stream_bytes);
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(carry) + packed_carry_bytes(ref_len));
+    BGSA_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, stride, kCodeRefill, 7, stream, &fault)) return rc;
+    auto kernel = semi ? bitpal_packed_blocked_kernel<NW, true> : bitpal_packed_blocked_kernel<NW, false>;
+    hipLaunchKernelGGL(kernel, dim3(blocked_workgroups()), dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
+                       static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
+                       (note_query_tile(blocked_q_tile(nq, read_count / kLanes)), blocked_q_tile(nq, read_count / kLanes)), stride, n_blocks, counter, fault);
+    BGSA_HIP_TRY(hipGetLastError());
+    return BGSA_HIP_OK;
+}
+
+// Column blocks in the set's carry form (a template so that only that form's row loops are instantiated).
+template <bool PACKED>
+int launch_blocks(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len, int read_len,
+                  int64_t read_count, int ref_start, int ref_end, int word_num, void *d_workspace, hipStream_t stream, int semi)
+{
+    int n_blocks = 0;
+    switch (pick_block_nw(word_num, &n_blocks)) {
+#define X(N)                                                                                                    \
+    case N:                                                                                                     \
+        if constexpr (PACKED)                                                                                   \
+            return launch_packed_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
+                                            ref_end, word_num, n_blocks, d_workspace, stream, semi);           \
+        else                                                                                                    \
+            return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,       \
+                                     ref_end, word_num, n_blocks, d_workspace, stream, semi);
+        BGSA_BITPAL_BLOCK_WIDTHS(X)
+#undef X
+    default: break;
+    }
+    set_error_text("bitpal: no column-block kernel for this word count");
+    return BGSA_HIP_EUNSUPPORTED;
 }
 
 inline int pick_q_tile(int nq, int64_t n_groups)
@@ -222,6 +343,7 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     const int q_tile = pick_q_tile(nq, n_groups);
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
@@ -247,7 +369,8 @@ const char *set_kernel_name(int word_num)
     static thread_local char name[64];
     if (word_num > kBitpalMaxPlain) {
         int n_blocks = 0;
-        snprintf(name, sizeof name, "bitpal_blocked_kernel<%d>", pick_block_nw(word_num, &n_blocks));
+        snprintf(name, sizeof name, kBitpalPackedBlocks ? "bitpal_packed_blocked_kernel<%d>" : "bitpal_blocked_kernel<%d>",
+                 pick_block_nw(word_num, &n_blocks));
         return name;
     }
     snprintf(name, sizeof name, "bitpal_asm_kernel<%d>", word_num);
@@ -258,18 +381,9 @@ int set_launch(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
                int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
                void *d_workspace, hipStream_t stream, int semi)
 {
-    if (word_num > kBitpalMaxPlain) {
-        int n_blocks = 0;
-        switch (pick_block_nw(word_num, &n_blocks)) {
-#define X(N)                                                                                     \
-    case N:                                                                                      \
-        return launch_blocked<N>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, \
-                                 ref_end, word_num, n_blocks, d_workspace, stream, semi);
-            BGSA_BITPAL_BLOCK_WIDTHS(X)
-#undef X
-        default: break;
-        }
-    }
+    if (word_num > kBitpalMaxPlain)
+        return launch_blocks<kBitpalPackedBlocks>(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end,
+                                                  word_num, d_workspace, stream, semi);
     switch (word_num) {
 #define X(N)                                                                                    \
     case N:                                                                                     \

@@ -34,6 +34,9 @@ void set_error(const char *what, hipError_t e, const char *file, int line)
 }
 void set_error_text(const char *text) { g_last_error = text; }
 
+static thread_local int g_last_q_tile = 0;
+void note_query_tile(int q_tile) { g_last_q_tile = q_tile; }
+
 void host_handle_reads(int algo, const char *rows, int64_t avail, int len, uint32_t *result_reads,
                        int word_num, int64_t read_count, int k, int threads);
 
@@ -210,8 +213,12 @@ static size_t plan_workspace_bytes(const Plan &plan, int ref_len, int read_len, 
     const int algo = plan.kernel;
     if (read_len > 0 && plan_beyond_registers(plan, (read_len + 31) / 32)) {  // column blocks: streams + carry buffers
         const int chains = algo == BGSA_ALGO_BITPAL ? plan.set->chains : 3;
+        // packed-carry blocks (score sets with many chains): carry_words words per direction and query ROW, one row spare
+        const size_t carries = (algo == BGSA_ALGO_BITPAL && plan.set->carry_words > 0)
+                                   ? static_cast<size_t>(ref_len + 1) * plan.set->carry_words * kLanes * sizeof(uint32_t) * kWavesPerBlock * blocked_workgroups()
+                                   : blocked_carry_bytes(ref_len, chains);
         const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
-                               blocked_carry_bytes(ref_len, chains) + 256;   // + the task counter
+                               carries + 256;   // + the task counter
         // the A/B state-in-memory kernels (BGSA_MYERS_IMPL=c / BGSA_BITPAL_IMPL=c) keep the DP state here
         const char *ab = getenv(algo == BGSA_ALGO_BITPAL ? "BGSA_BITPAL_IMPL" : "BGSA_MYERS_IMPL");
         const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
@@ -701,6 +708,8 @@ int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, 
         }
     return n;
 }
+
+int bgsa_hip_last_query_tile(void) { return g_last_q_tile; }
 
 const char *bgsa_hip_kernel_name(int algo, int word_num)
 {

@@ -25,6 +25,7 @@ label differences.
 """
 from __future__ import annotations
 
+import os
 import sys
 from pathlib import Path
 
@@ -66,6 +67,38 @@ def dispatch() -> list[str]:
         f"s_addc_u32 {S_PC_HI}, {S_BASE_HI}, 0",
         f"s_setpc_b64 {S_PC}",
     ]
+
+
+def weave_dispatch(body_lines: list[str], disp_lines: list[str], tail: int = 14) -> list[str]:
+    """A row body followed by the dispatch of the next token, with the dispatch's scalar instructions placed BETWEEN the
+    body's last vector instructions instead of behind them.  The five scalar instructions that turn the next stream code
+    into a jump target are a dependent chain (s_and -> s_mul -> s_add -> s_addc) in front of a taken branch: behind the
+    body they are some 40 cycles in which this wave feeds the vector pipe nothing, and a SIMD needs two waves ready at
+    any time to issue a vector instruction every other cycle.  Between vector instructions they cost issue slots only.
+    Measured (round 3, same box, scripts/r03_weave_ab.sh): it pays where the row is SHORT — the banded loop, whose token
+    holds 48 vector instructions — and not where a row is hundreds of them: Myers 150 bp 1046.1 -> 1047.9 ms, 1000 bp
+    5100.9 -> 5221.3 ms (two waves per SIMD: the scalar instructions between the links of the VCC chains cost more than the
+    bubble they hide), BitPAl unchanged, column blocks at 2,000 bp 42.3 -> 44.4 s.  So only the banded loops use it.
+    Nothing that writes SCC may sit between s_add_u32 and s_addc_u32: the bodies hold VALU instructions, s_nop and
+    `s_mov_b64 vcc` only — checked here."""
+    scalars, jump = disp_lines[:-1], disp_lines[-1]
+    assert jump.startswith("s_setpc_b64")
+    n = len(body_lines)
+    first = max(0, n - tail)
+    for ln in body_lines[first:]:
+        assert ln.startswith(("v_", "s_nop", "s_mov_b64 vcc", "global_")), f"instruction with unknown SCC behaviour in a woven tail: {ln}"
+    slots = n - first
+    gap = max(1, slots // (len(scalars) + 1))
+    out = list(body_lines[:first])
+    k_next = 0
+    for i, ln in enumerate(body_lines[first:]):
+        out.append(ln)
+        if k_next < len(scalars) and (i + 1) % gap == 0 and i + 1 < slots:
+            out.append(scalars[k_next])
+            k_next += 1
+    out += scalars[k_next:]
+    out.append(jump)
+    return out
 
 
 def fail_slot() -> list[str]:
@@ -539,7 +572,8 @@ def gen_banded_cut_function(groups: int) -> str:
     S_ANY, S_VCC1, S_CNT2 = "s[58:59]", "s[98:99]", "s57"   # (s100 / s101 are reserved by the compiler)
     S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
     S_CHUNK, S_PUSHROW, S_PUSHMAX, S_EARLY = "s92", "s93", "s94", "s95"
-    clobbers = ["s57", "s58", "s59"] + CLOBBERS[:-3] + [f"s{i}" for i in range(72, 100)] + ["vcc", "scc", "memory"]
+    S_PUSHSOLID, S_THRSOLID = "s56", "s55"
+    clobbers = ["s55", "s56", "s57", "s58", "s59"] + CLOBBERS[:-3] + [f"s{i}" for i in range(72, 100)] + ["vcc", "scc", "memory"]
 
     def reg_for(c: int):
         def reg(name: str) -> str:
@@ -589,21 +623,37 @@ def gen_banded_cut_function(groups: int) -> str:
         """reject masks = the lanes that are not alive."""
         return [f"s_andn2_b64 {S_DEAD[g]}, exec, {S_ALIVE[g]}" for g in range(G)]
 
-    def push_or(label_no: str) -> list[str]:
-        """Few survivors late enough: the wave stops here and hands them to the regroup list (banded.hip)."""
+    def push_or(label_no: str, tag: str) -> list[str]:
+        """Few lanes within the limit, late enough: the wave stops here and hands them to the regroup list (banded.hip).
+        Late enough = from row S_PUSHROW on (random pairs are dead by then: whatever is alive mostly stays alive), or
+        already from row S_PUSHSOLID on if one of the alive lanes is a SOLID survivor — its error count at most S_THRSOLID.
+        Between those rows the lanes still alive among random pairs are stragglers about to cross the limit: pushing them
+        costs each a share of a dense pass for nothing (10k x 1M random pairs, pushing from row k + 40 without this test:
+        88 -> 92 ms), while a wave that does hold a real survivor gains the rows it no longer runs for it (1 % dense
+        survivors: 145 -> 133 ms)."""
         out = [
             f"s_lshl_b32 {S_CNT}, {S_CHUNK}, 5",
             f"s_add_u32 {S_CNT}, {S_CNT}, {S_CUT}",
             f"s_add_u32 {S_CNT}, {S_CNT}, {S_SH}",
-            f"s_cmp_ge_u32 {S_CNT}, {S_PUSHROW}",
+            f"s_cmp_ge_u32 {S_CNT}, {S_PUSHSOLID}",
             f"s_cbranch_scc0 {label_no}",
-            f"s_bcnt1_i32_b64 {S_CNT}, {S_ALIVE[0]}",
+            f"s_bcnt1_i32_b64 {S_CNT2}, {S_ALIVE[0]}",
         ]
         if G == 2:
-            out += [f"s_bcnt1_i32_b64 {S_CNT2}, {S_ALIVE[1]}", f"s_add_u32 {S_CNT}, {S_CNT}, {S_CNT2}"]
+            out += [f"s_bcnt1_i32_b64 {S_C}, {S_ALIVE[1]}", f"s_add_u32 {S_CNT2}, {S_CNT2}, {S_C}"]
         out += [
-            f"s_cmp_le_u32 {S_CNT}, {S_PUSHMAX}",
+            f"s_cmp_le_u32 {S_CNT2}, {S_PUSHMAX}",
             f"s_cbranch_scc0 {label_no}",
+            f"s_cmp_ge_u32 {S_CNT}, {S_PUSHROW}",
+            f"s_cbranch_scc1 L_push_{tag}_%=",
+            f"v_cmp_ge_u32 vcc, {S_THRSOLID}, %[s{acc[0]}]",
+        ]
+        if G == 2:
+            out += [f"v_cmp_ge_u32_e64 {S_ANY}, {S_THRSOLID}, %[s{acc[1]}]", "s_nop 1", f"s_or_b64 vcc, vcc, {S_ANY}"]
+        out += [
+            "s_cmp_lg_u64 vcc, 0",
+            f"s_cbranch_scc0 {label_no}",
+            f"L_push_{tag}_%=:",
         ]
         out += latch_from_alive()
         out += [f"s_mov_b32 {S_EARLY}, 1", "s_branch L_done_%="]
@@ -622,6 +672,8 @@ def gen_banded_cut_function(groups: int) -> str:
         f"s_mov_b32 {S_EARLY}, 0",
         f"s_mov_b32 {S_PUSHROW}, %[pushrow]",
         f"s_mov_b32 {S_PUSHMAX}, %[pushmax]",
+        f"s_mov_b32 {S_PUSHSOLID}, %[pushsolid]",
+        f"s_mov_b32 {S_THRSOLID}, %[solidthr]",
     ]
     asm += [f"s_mov_b64 {S_DEAD[g]}, 0" for g in range(G)]
     asm += [f"s_mov_b64 {S_BASE[c]}, %[base{c}]" for c in range(5)]
@@ -646,6 +698,8 @@ def gen_banded_cut_function(groups: int) -> str:
         cycle).  Woven between the row's vector instructions they cost issue slots only; the row's shift counter moves up
         right behind the instructions that read it, so nothing but VALU sits between s_add and s_addc (SCC)."""
         rows = body.emit_asm(reg_for(c), c)
+        if os.environ.get("BGSA_GEN_BANDED_WEAVE", "1") == "0":   # A/B builds: the dispatch behind the row
+            return rows + [f"s_add_u32 {S_SH}, {S_SH}, 1"] + disp()
         head, rest = rows[:G], rows[G:]                      # the G window shifts read S_SH
         out = head + [f"s_add_u32 {S_SH}, {S_SH}, 1"]
         d = disp()
@@ -703,7 +757,7 @@ def gen_banded_cut_function(groups: int) -> str:
     ]
     asm += test("p") + alive()
     asm += ["s_cbranch_scc0 L_ev_alldead_%="]
-    asm += push_or("L_ev_out_%=")
+    asm += push_or("L_ev_out_%=", "p")
     asm += ["L_ev_alldead_%=:"] + [f"s_mov_b64 {S_DEAD[g]}, exec" for g in range(G)] + ["s_branch L_done_%="]
     asm += [
         "L_ev_general_%=:",
@@ -716,7 +770,7 @@ def gen_banded_cut_function(groups: int) -> str:
             "s_cbranch_scc0 L_ev_nolatch_%="]
     asm += latch_from_alive()
     asm += ["L_ev_nolatch_%=:"]
-    asm += push_or("L_ev_reset_%=")
+    asm += push_or("L_ev_reset_%=", "g")
     asm += [
         "L_ev_reset_%=:",
         f"s_bitcmp1_b32 {S_ARG}, 0",          # bit 0: scoring starts (row k)
@@ -764,7 +818,7 @@ def gen_banded_cut_function(groups: int) -> str:
     outs += ['[left] "=s"(left)', '[early] "=s"(early)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
     ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[vmask] "v"(band_mask)', '[thr] "s"(limit)', '[cutrows] "s"(cut_rows)',
-           '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)']
+           '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)', '[pushsolid] "s"(push_row_solid)', '[solidthr] "s"(solid_limit)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
     clob = ", ".join(f'"{x}"' for x in clobbers)
     return f"""
@@ -774,12 +828,13 @@ def gen_banded_cut_function(groups: int) -> str:
 // target, fetched by the loop itself: no input)}} of class c's offset match string; voff[g] = byte offset of word i + 2 relative
 // to base[c] (group 1: the group stride included); dead[g] = reject mask of group g (lanes whose error count passed `limit` at the last
 // checkpoint, or all lanes if the wave stopped with every lane of every group past it); left / early as banded_rows_asm32
-// (early: the lanes NOT in dead[] go to the regroup list).
+// (early: the lanes NOT in dead[] go to the regroup list; from row push_row on whenever 1..push_max lanes are within the
+// limit, from row push_row_solid on if one of them has at most solid_limit errors since row k).
 __device__ __forceinline__ void banded_cut_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][4], uint32_t (&voff)[{G}],
                                                        const unsigned long long (&base)[5],
                                                        const unsigned long long stream, const int n_windows,
                                                        const uint32_t band_mask, const uint32_t cut_rows,
-                                                       const uint32_t limit, const uint32_t push_row,
+                                                       const uint32_t limit, const uint32_t push_row, const uint32_t push_row_solid, const uint32_t solid_limit,
                                                        const uint32_t push_max, unsigned long long (&dead)[{G}],
                                                        int &left, int &early)
 {{
@@ -1115,11 +1170,119 @@ __device__ __forceinline__ int {fn_name}<{nw}>(uint32_t (&state)[{n_state}], {ma
 """
 
 
-def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int]]:
-    """Kernel widths for one score set: plain kernels (state in registers for the whole subject) for
-    1..P words, P the widest that fits the VGPR budget (at most 12; measured for 2/-3/-5: 9-11 words at
-    two waves per SIMD run at 27.8-28.5 TCUPS against 24.5 for the same subjects as column blocks), and
-    column-block kernels for the four widths up to W <= 8 (a block also carries 2 x chains carry words)."""
+def gen_packed_blocked_function(fn_name: str, nw: int, body: R.Body, n_base: int, n_words: int, n_eq: int) -> str:
+    """Row loop of a packed-carry column-block kernel (rows_ir.make_blocked_packed): the carries of one row are bits of
+    n_words words per direction, exchanged with the neighbouring blocks EVERY row.  Plain stream (codes 0..4, END,
+    REFILL; no CARRY token).  State = n_base block registers, n_words carry-in words, n_words carry-out words; operand
+    `nxt` = the carry-in words of the NEXT row, fetched while this row is computed.  Per row: wait for the words
+    fetched one row ago, move them in, fetch the next row's, run the body, store the carry-out words over this row's
+    carry-in words (the block to the right reads them there), advance the row offset.  The buffer holds one row more
+    than the query has, so the last row's fetch stays inside it."""
+    slot_of, n_slots = body.allocate_temps()
+    S_CB = "s[80:81]"
+    clobbers = CLOBBERS[:-3] + ["s80", "s81", "vcc", "scc", "memory"]
+    cin = [n_base + j for j in range(n_words)]
+    cout = [n_base + n_words + j for j in range(n_words)]
+    row_bytes = 256 * n_words
+
+    def reg_for(c: int):
+        def reg(name: str) -> str:
+            if name.startswith("S"):
+                return f"%[s{name[1:]}]"
+            if name.startswith("E"):
+                return f"%[e{c}_{name[1:]}]"
+            return f"%[t{slot_of[name]}]"
+        return reg
+
+    def row(c: int) -> list[str]:
+        pre = ["s_waitcnt vmcnt(0)"]
+        pre += [f"v_mov_b32 %[s{cin[j]}], %[n{j}]" for j in range(n_words)]
+        pre += [f"global_load_dword %[n{j}], %[voff], {S_CB} offset:{row_bytes + 256 * j} sc1" for j in range(n_words)]
+        post = [f"global_store_dword %[voff], %[s{cout[j]}], {S_CB} offset:{256 * j}" for j in range(n_words)]
+        post.append(f"v_add_u32 %[voff], 0x{row_bytes:x}, %[voff]")
+        return pre + body.emit_asm(reg_for(c), c) + post + dispatch()
+
+    asm = [
+        f"s_mov_b64 {S_PTR}, %[qp]",
+        f"s_mov_b32 {S_LEFT}, %[nwin]",
+        f"s_load_dwordx2 {S_WIN}, {S_PTR}, 0x0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+        f"s_mov_b64 {S_CB}, %[cbase]",
+        f"s_getpc_b64 {S_PC}",
+        "L_anchor_%=:",
+        f"s_add_u32 {S_BASE_LO}, {S_PC_LO}, (L_body0_%= - L_anchor_%=)",
+        f"s_addc_u32 {S_BASE_HI}, {S_PC_HI}, 0",
+        "s_waitcnt lgkmcnt(0)",
+    ]
+    asm += dispatch()
+    for c in range(5):
+        asm.append(f"L_body{c}_%=:")
+        asm += row(c)
+    asm.append("L_body5_%=:")
+    asm.append("s_branch L_done_%=")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - 4) / 4, 4, 0xbf800000")
+    asm.append("L_body6_%=:")
+    asm += [
+        f"s_sub_u32 {S_LEFT}, {S_LEFT}, 1",
+        "s_cbranch_scc1 L_done_%=",
+        "s_waitcnt lgkmcnt(0)",
+        f"s_mov_b64 {S_WIN}, {S_NXT}",
+        f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 8",
+        f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0",
+        f"s_load_dwordx2 {S_NXT}, {S_PTR}, 0x8",
+    ]
+    asm += dispatch()
+    asm.append("L_refill_end_%=:")
+    asm.append(".fill ((L_body1_%= - L_body0_%=) - (L_refill_end_%= - L_body6_%=)) / 4, 4, 0xbf800000")
+    asm.append("L_body7_%=:")
+    asm += fail_slot()
+    asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")
+
+    n_state = n_base + 2 * n_words
+    text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
+    outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
+    outs += [f'[n{j}] "+v"(next_in[{j}])' for j in range(n_words)]
+    outs += ['[voff] "+v"(voff)', '[left] "=s"(left)']
+    outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
+    ins = [f'[e{c}_{j}] "v"(P[{c}][{j}])' for c in range(5) for j in range(n_eq)]
+    ins += ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[cbase] "s"(carry_base)']
+    clob = ", ".join(f'"{x}"' for x in clobbers)
+    return f"""
+// {body.valu_count()} VALU per row, {n_slots} temporaries, {n_words} packed carry word(s) per direction
+template <>
+__device__ __forceinline__ int {fn_name}<{nw}>(uint32_t (&state)[{n_state}], const uint32_t (&P)[5][{n_eq}],
+                                                       uint32_t (&next_in)[{n_words}], uint32_t &voff,
+                                                       const unsigned long long carry_base,
+                                                       const unsigned long long stream, const int n_windows)
+{{
+    uint32_t tmp[{max(n_slots, 1)}];
+    int left;
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+    return left;
+}}
+"""
+
+
+class BitpalDomainError(ValueError):
+    """A score set whose kernels do not fit the register file: says which quantity is over which budget."""
+
+
+def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int], bool]:
+    """Kernel widths for one score set: (plain widths, column-block widths, packed).
+
+    Plain kernels (state in registers for the whole subject) for 1..P words, P the widest that fits the VGPR budget (at
+    most 12; measured for 2/-3/-5: 9-11 words at two waves per SIMD run at 27.8-28.5 TCUPS against 24.5 for the same
+    subjects as column blocks).  Column-block kernels for longer subjects: the four widths up to W <= 8 words in the
+    per-chain carry form (a block also carries 2 x chains carry words — round 2's only form), or, for score sets
+    with so many chains that not even a one-word block fits that way (match - mismatch >= ~12: chains = 1 + 2 (M - I - 1) +
+    bits(M - 2G)), in the PACKED carry form (rows_ir.make_blocked_packed: ceil(chains / 32) words per direction
+    whatever the set).  What bounds the domain then is the row body itself: it keeps M - I one-hot class masks and as
+    many incoming-value masks of one word alive at once, so a one-word body needs about 2 (M - I) + bits(M - 2G) + 16
+    registers — M - I up to ~100 fits.  Raises BitpalDomainError beyond that."""
     def plain_regs(nw):
         return sc.planes * nw + 5 * nw + R.bitpal_body(nw, sc).allocate_temps()[1]
 
@@ -1130,15 +1293,44 @@ def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int]]:
         # measured 24 / 39 / 44 / 75 registers for 3 / 10 / 13 / 22 chains
         return asm_operands + 20 + (5 * sc.chains + 1) // 2
 
-    plain = max(nw for nw in range(1, 13) if plain_regs(nw) <= BITPAL_VGPR_BUDGET)
-    wide = max(nw for nw in range(1, 9) if block_regs(nw) <= BITPAL_BLOCK_VGPR_BUDGET)
-    return list(range(1, plain + 1)), list(range(max(1, wide - 3), wide + 1))
+    def packed_regs(nw):
+        body, _, n_words = R.bitpal_packed_block_body(nw, sc)
+        return sc.planes * nw + 5 * nw + body.allocate_temps()[1] + 3 * n_words + 2 + 24
+
+    def fitting(regs, budget, upto):
+        """Widths 1..upto whose register need is within the budget (the need grows with the width: stop at the first miss)."""
+        out = []
+        for nw in range(1, upto + 1):
+            if regs(nw) > budget:
+                break
+            out.append(nw)
+        return out
+
+    fits_plain = fitting(plain_regs, BITPAL_VGPR_BUDGET, 12)
+    if not fits_plain:
+        raise BitpalDomainError(
+            f"BitPAl {sc.match}/{sc.mismatch}/{sc.gap}: the row body of ONE word needs {plain_regs(1)} VGPRs "
+            f"(budget {BITPAL_VGPR_BUDGET}): match - mismatch = {sc.K} value classes (two masks each) and "
+            f"bits(match - 2 gap) = {sc.nb} planes are over what a wave can hold")
+    plain = max(fits_plain)
+    fits_block = fitting(block_regs, BITPAL_BLOCK_VGPR_BUDGET, 8)
+    if fits_block:
+        wide = max(fits_block)
+        return list(range(1, plain + 1)), list(range(max(1, wide - 3), wide + 1)), False
+    fits_packed = fitting(packed_regs, BITPAL_VGPR_BUDGET, 8)
+    if not fits_packed:
+        raise BitpalDomainError(
+            f"BitPAl {sc.match}/{sc.mismatch}/{sc.gap}: no column-block kernel fits: one word needs {packed_regs(1)} VGPRs "
+            f"in the packed carry form (budget {BITPAL_VGPR_BUDGET}; match - mismatch = {sc.K}, {sc.chains} carry chains)")
+    wide = max(fits_packed)
+    return list(range(1, plain + 1)), list(range(max(1, wide - 3), wide + 1)), True
 
 
 def bitpal_inc_text(sc: R.BitpalScores) -> str:
     """The generated header of one BitPAl score set: constants + row loops of every width."""
     B, NC = sc.planes, sc.chains
-    plain, blocks = bitpal_widths(sc)
+    plain, blocks, packed = bitpal_widths(sc)
+    NCW = (NC + 31) // 32
     per_word = R.bitpal_body(1, sc).valu_count()
     case = lambda ws: " ".join(f"X({w})" for w in ws)
     parts = ["// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n",
@@ -1151,6 +1343,8 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
              f"constexpr int kBitpalValuPerWord = {per_word};\n"
              f"constexpr int kBitpalMaxPlain = {plain[-1]};   // widest kernel that keeps the whole subject in registers\n"
              f"constexpr int kBitpalBlockMin = {blocks[0]}, kBitpalBlockMax = {blocks[-1]};   // column-block widths\n"
+             f"constexpr bool kBitpalPackedBlocks = {'true' if packed else 'false'};   // carries of a row packed into kBitpalCarryWords words (many chains)\n"
+             f"constexpr int kBitpalCarryWords = {NCW};\n"
              f"constexpr int kBitpalWeights[{B}] = {{{', '.join(str(x) for x in sc.weights())}}};   // score weight of a set bit per plane\n"
              f"#define BGSA_BITPAL_PLAIN_WIDTHS(X) {case(plain)}\n"
              f"#define BGSA_BITPAL_BLOCK_WIDTHS(X) {case(blocks)}\n"
@@ -1170,15 +1364,31 @@ def bitpal_inc_text(sc: R.BitpalScores) -> str:
                  "                                                      const uint32_t (&P)[5][NW], uint32_t &voff,\n"
                  "                                                      const unsigned long long carry_base,\n"
                  "                                                      const unsigned long long stream, const int n_windows);\n")
+    parts.append("\n// The same with the carries of a row packed into kBitpalCarryWords words per direction, exchanged every row\n"
+                 "// (rows_ir.py: make_blocked_packed): for score sets with too many chains for a register pair each.\n"
+                 "// state = planes x NW, carry-in words, carry-out words; next_in = the next row's carry-in words;\n"
+                 "// carry buffer = [row][word][64 lanes] dwords at carry_base, voff = this lane's byte offset of the current row.\n"
+                 "template <int NW>\n"
+                 "__device__ __forceinline__ int bitpal_packed_block_rows_asm(uint32_t (&state)[kBitpalPlanes * NW + 2 * kBitpalCarryWords],\n"
+                 "                                                             const uint32_t (&P)[5][NW], uint32_t (&next_in)[kBitpalCarryWords],\n"
+                 "                                                             uint32_t &voff, const unsigned long long carry_base,\n"
+                 "                                                             const unsigned long long stream, const int n_windows);\n")
     for nw in blocks:
-        blocked, init = R.bitpal_block_body(nw, sc)
-        assert len(init) == NC and not any(init)  # every BitPAl chain starts with carry-in 0
-        parts.append(gen_blocked_function("bitpal_block_rows_asm", nw, blocked, B * nw, NC, 0, nw))
+        if packed:
+            body, init, n_words = R.bitpal_packed_block_body(nw, sc)
+            assert len(init) == NC and not any(init) and n_words == NCW
+            parts.append(gen_packed_blocked_function("bitpal_packed_block_rows_asm", nw, body, B * nw, n_words, nw))
+        else:
+            blocked, init = R.bitpal_block_body(nw, sc)
+            assert len(init) == NC and not any(init)  # every BitPAl chain starts with carry-in 0
+            parts.append(gen_blocked_function("bitpal_block_rows_asm", nw, blocked, B * nw, NC, 0, nw))
     return "".join(parts)
 
 
 def main() -> int:
-    here = Path(__file__).resolve().parent
+    # `--out DIR`: write the three headers there instead of beside this script (tests/test_generated_inc_cpu.py compares them
+    # with the committed ones)
+    here = Path(sys.argv[sys.argv.index("--out") + 1]) if "--out" in sys.argv else Path(__file__).resolve().parent
     head = "// GENERATED by gen_rows_asm.py from rows_ir.py — do not edit.\n"
     # ---- Myers --------------------------------------------------------------------------------
     parts = [head,

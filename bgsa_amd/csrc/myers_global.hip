@@ -592,6 +592,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     const int q_tile = pick_q_tile(nq, n_groups);
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
@@ -621,6 +622,7 @@ int launch_semi_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_res
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     const int q_tile = pick_q_tile(nq, n_groups);
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
@@ -647,6 +649,7 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
     const int64_t n_groups = read_count / kLanes;
     int q_tile = 8;  // a task is already long: 8 queries x ref_len rows x 11*NW instructions
     while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {
@@ -688,7 +691,7 @@ int launch_blocked(const char *d_content, const uint32_t *d_peq, int16_t *d_resu
     hipLaunchKernelGGL((myers_blocked_kernel<NW, PEQ, SEMI>), dim3(blocked_workgroups()), dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, carry, ref_len, read_len,
                        static_cast<long long>(read_count), static_cast<int>(read_count / kLanes), word_num, nq,
-                       blocked_q_tile(nq, read_count / kLanes),
+                       (note_query_tile(blocked_q_tile(nq, read_count / kLanes)), blocked_q_tile(nq, read_count / kLanes)),
                        stride, n_blocks, counter, fault);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
@@ -750,6 +753,7 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     const int q_tile = pick_q_tile(nq, n_groups);
+    note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
     if (grid.y > 65535u) {

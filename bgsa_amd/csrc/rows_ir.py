@@ -83,6 +83,7 @@ class Body:
     def LSHR1(self, d, a): return self._emit("lshr1", d, a)            # d = a >> 1 (slow class)
     def ALIGNBIT(self, d, hi, lo, sh): return self._emit("alignbit", d, hi, lo, sh)  # ({hi,lo} >> sh)[31:0], sh scalar
     def LSHRS(self, d, a, sh): return self._emit("lshrs", d, a, sh)   # d = a >> sh, sh scalar (VOP2 v_lshrrev_b32: fast class)
+    def LSHL_IMM(self, d, a, n): return self._emit("lshl_imm", d, a, imm=n)   # d = a << n, n an immediate (slow class)
 
     def MATCH3(self, d, b0, b1, b2, wild=False):
         """d = columns whose 3-bit character code (b2 b1 b0) equals the row's class (0..4 = A C G T
@@ -172,6 +173,7 @@ class Body:
             elif k == "add": wr(op.dst, (s[0].astype(np.uint64) + s[1].astype(np.uint64)) & np.uint64(0xFFFFFFFF))
             elif k == "lshr1": wr(op.dst, s[0] >> np.uint32(1))
             elif k == "lshrs": wr(op.dst, s[0] >> s[1].astype(np.uint32))
+            elif k == "lshl_imm": wr(op.dst, (s[0].astype(np.uint64) << np.uint64(op.imm)) & np.uint64(0xFFFFFFFF))
             elif k == "alignbit":
                 pair = (s[0].astype(np.uint64) << np.uint64(32)) | s[1].astype(np.uint64)
                 wr(op.dst, (pair >> s[2].astype(np.uint64)) & np.uint64(0xFFFFFFFF))
@@ -230,6 +232,7 @@ class Body:
             elif k == "lshr1": lines.append(f"v_lshrrev_b32 {d}, 1, {r[0]}")
             elif k == "alignbit": lines.append(f"v_alignbit_b32 {d}, {r[0]}, {r[1]}, {r[2]}")
             elif k == "lshrs": lines.append(f"v_lshrrev_b32 {d}, {r[1]}, {r[0]}")
+            elif k == "lshl_imm": lines.append(f"v_lshlrev_b32 {d}, {op.imm}, {r[0]}")
             elif k == "bitop3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm:02x}")
             elif k == "match3": lines.append(f"v_bitop3_b32 {d}, {r[0]}, {r[1]}, {r[2]} bitop3:0x{op.imm[cls]:02x}")
             elif k == "add_co": lines.append(f"v_add_co_u32 {d}, vcc, {r[0]}, {r[1]}")
@@ -1280,8 +1283,9 @@ class _Bool:
         return cur
 
 
+@__import__("functools").lru_cache(maxsize=256)
 def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
-    """Row body for `nw` words.  State S[w*B + i] = plane i (weight 2^i) of the UNSIGNED value u of word
+    """(Memoised: callers treat the returned Body as read-only.)  Row body for `nw` words.  State S[w*B + i] = plane i (weight 2^i) of the UNSIGNED value u of word
     w's 32 columns, B = sc.planes = bits(C) (the reference keeps the two's complement of -u in one more
     plane, align_core.c:191-214; the unsigned form saves that plane and four instructions per word).
     E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed shift and its
@@ -1543,6 +1547,93 @@ def make_blocked(body: Body, n_state: int):
     if open_chain is not None:
         out.ADDC(f"S{n_state + n + open_chain}", f"S{n_state + n + open_chain}", f"S{n_state + n + open_chain}")
     return out, [c for _, c in chains]
+
+
+def make_blocked_packed(body: Body, n_state: int):
+    """Column-block form for bodies with MANY carry chains: the carries of one row travel as bits of a few words —
+    chain k in word k // 32, first chain in bit 31 — instead of one word per chain and 32 rows (make_blocked), which
+    costs two registers per chain: 86 for the 43 chains of 10/-9/-15, more than a column-block kernel can hold.
+    Here the block holds ceil(chains / 32) carry-in words and as many carry-out words whatever the score set:
+    chain k takes its carry-in with `x + x` on S[n_state + k // 32] (VCC = the word's top bit) and appends its
+    carry-out with `x + x + vcc` on S[n_state + W + k // 32]; a last, partly filled word is moved up at the end of the
+    row so that its first chain sits in bit 31 again.  The words are exchanged with the neighbouring blocks EVERY
+    row (the row loop loads the next row's words while it computes this one's and stores its own behind the body):
+    two or three loads and stores per row against hundreds of vector instructions.  Returns (body, initial carry-in
+    bit per chain, words)."""
+    chains = []
+    for i, op in enumerate(body.ops):
+        if op.kind == "add_co":
+            chains.append((i, 0))
+        elif op.kind == "setc1":
+            chains.append((i, 1))
+    n = len(chains)
+    n_words = (n + 31) // 32
+    starts = {i: k for k, (i, _) in enumerate(chains)}
+    cin = lambda k: f"S{n_state + k // 32}"
+    cout = lambda k: f"S{n_state + n_words + k // 32}"
+    out = Body()
+    open_chain = None
+    for i, op in enumerate(body.ops):
+        if i in starts:
+            if open_chain is not None:
+                out.ADDC(cout(open_chain), cout(open_chain), cout(open_chain))
+            k = starts[i]
+            out.ADD_CO(cin(k), cin(k), cin(k))
+            open_chain = k
+            if op.kind == "add_co":
+                out.ops.append(Op("addc", op.dst, op.srcs, 0))
+            continue
+        out.ops.append(op)
+    if open_chain is not None:
+        out.ADDC(cout(open_chain), cout(open_chain), cout(open_chain))
+    if n % 32:
+        last = f"S{n_state + 2 * n_words - 1}"
+        out.LSHL_IMM(last, last, 32 - n % 32)
+    return out, [c for _, c in chains], n_words
+
+
+def bitpal_packed_block_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT):
+    """Packed-carry column-block form of bitpal_body: (body, initial carry-in per chain, carry words per direction)."""
+    body, init, n_words = make_blocked_packed(bitpal_body(nw, sc), sc.planes * nw)
+    return schedule(body, 200), init, n_words
+
+
+def bitpal_packed_blocked_simulate(subjects: np.ndarray, query: np.ndarray, nw_block: int,
+                                   sc: BitpalScores = BITPAL_DEFAULT, semi: bool = False) -> np.ndarray:
+    """bitpal_packed_blocked_kernel at toy scale: column blocks of nw_block words, per query row the carry words of
+    the block to the left are this block's carry-in words and its own carry-out words replace them."""
+    n, slen = subjects.shape
+    qlen = len(query)
+    B = sc.planes
+    nw_total = (slen + 31) // 32
+    n_blocks = (nw_total + nw_block - 1) // nw_block
+    peq = build_peq32(subjects, n_blocks * nw_block)
+    body, init, n_words = bitpal_packed_block_body(nw_block, sc)
+    assert not any(init) and n_words == (sc.chains + 31) // 32
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
+    carry = [[np.zeros(n, np.uint32) for _ in range(n_words)] for _ in range(qlen)]   # [row][word]
+    run = np.full(n, sc.gap * qlen, dtype=np.int64)
+    best = run.copy()
+    score = np.full(n, sc.gap * (qlen + slen), dtype=np.int64)
+    base = B * nw_block
+    for blk in range(n_blocks):
+        st = bitpal_init_state(nw_block, n, sc, semi) + [np.zeros(n, np.uint32) for _ in range(2 * n_words)]
+        for r, ch in enumerate(query):
+            for j in range(n_words):
+                st[base + j] = carry[r][j].copy()
+            c = code.get(int(ch), 0)
+            body.simulate(st, [peq[c, blk * nw_block + w] for w in range(nw_block)])
+            carry[r] = [st[base + n_words + j].copy() for j in range(n_words)]
+        for w in range(nw_block):
+            cols = min(32, max(0, slen - 32 * (blk * nw_block + w)))
+            if cols == 0:
+                continue
+            vals = bitpal_column_values(st, w, sc)[:, :cols]
+            steps = run[:, None] + np.cumsum(vals + sc.gap, axis=1)
+            best = np.maximum(best, steps.max(axis=1))
+            run = steps[:, -1]
+            score += vals.sum(axis=1)
+    return (best if semi else score).astype(np.int16)
 
 
 def bitpal_block_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT):

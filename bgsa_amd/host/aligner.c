@@ -17,7 +17,8 @@
  *     int device count, int64 query count, then per bucket int64 reads + int padded reads
  *     (cal_cpu.c:247-249,350-351) — exactly what the reference's `convert -r` reads;
  *   * the report printed at the end keeps the reference's lines and its two GCUPS figures
- *     (cal_cpu.c:459-475): "cal" = time inside the scoring calls, "Total" = wall.
+ *     (cal_cpu.c:459-475): "cal" = time spent scoring (GPU time of the scoring launches, the reference's
+ *     cal_total_times around its compute call, cal_cpu.c:111-118), "Total" = wall.
  *
  * The subject bucket lives in HBM: rows are uploaded once, preprocessed on the GPU, and every
  * query block is one asynchronous launch; a writer thread drains finished score blocks to disk
@@ -43,6 +44,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -96,16 +98,25 @@ typedef struct {
     int head, tail, done;
     int fd;           /* the result file; blocks are written at their own offsets by several threads at once */
     int64_t offset;   /* file offset of the next block */
+    char *map;        /* the whole result file mapped MAP_SHARED (NULL: the pwrite() path) */
     int n_writers;
     double seconds;
     pthread_mutex_t lock;
     pthread_cond_t cond;
 } ring_t;
 
-/* A block goes to the file with pwrite() at its own offset, optionally as BGSA_WRITER_THREADS concurrent slices.
- * Default 1: the result file is what bounds Total GCUPS (10k x 1M Myers: the GPU produces 19 GB/s of scores, one
- * stream into a tmpfs page cache takes 6.4 GB/s), but more streams do not help there — 4 / 8 / 16 threads measured
- * 5.0 / 5.9 / 3.4 s against 3.1 s with one (page-cache allocation serialises); a striped file system may differ. */
+/* The result file is what bounds Total GCUPS: at 10k x 1M Myers the GPU produces 19 GB/s of scores.
+ * pwrite() (the default): one stream into a tmpfs page cache takes 6.4 GB/s, and more streams make it WORSE — 4 / 8 / 16
+ * threads measured 5.0 / 5.9 / 3.4 s against 3.1 s with one (round 2) — because write() holds the file's inode lock for
+ * the whole call: concurrent writes to one file take turns, and pay for the hand-over.
+ * BGSA_WRITER_MODE=mmap (round 3, measured and NOT the default): the file is sized up front (its final size is known from
+ * the bucket plan), mapped MAP_SHARED, and a block is copied into the mapping by BGSA_WRITER_THREADS threads (default 8),
+ * each faulting in its own pages — page faults take no inode lock.  10k x 1M into /dev/shm (profiles/r03_writer.txt):
+ * 5.08 / 4.57 / 5.02 / 5.51 s of writing with 1 / 4 / 8 / 16 threads against 3.51 s for the single pwrite() stream: a
+ * page of a shared mapping arrives through a fault (about a microsecond each, five million of them), zeroed first, and
+ * the faults of one file do not scale over threads either.  (`mmap+populate` faults each slice in with one
+ * madvise(MADV_POPULATE_WRITE) instead.)  So the page cache of one tmpfs file takes about 6 GB/s whichever way the bytes
+ * arrive, and Total GCUPS of a 20 GB result stays near 60-70k while the kernels (cal) run at 200k+. */
 typedef struct {
     int fd;
     const char *src;
@@ -113,6 +124,21 @@ typedef struct {
     int64_t offset;
     int failed;
 } slice_t;
+
+static int g_populate = 0;   /* BGSA_WRITER_MODE=mmap+populate: fault the slice's pages in with one madvise() before the copy */
+static void *copy_slice(void *arg)
+{
+    slice_t *w = (slice_t *)arg;   /* fd < 0: `offset` holds the destination address */
+    char *dst = (char *)(intptr_t)w->offset;
+#ifdef MADV_POPULATE_WRITE
+    if (g_populate) {
+        char *lo = (char *)(((uintptr_t)dst + 4095) & ~(uintptr_t)4095), *hi = (char *)(((uintptr_t)dst + w->bytes) & ~(uintptr_t)4095);
+        if (hi > lo) (void)madvise(lo, (size_t)(hi - lo), MADV_POPULATE_WRITE);
+    }
+#endif
+    memcpy(dst, w->src, w->bytes);
+    return NULL;
+}
 
 static void *write_slice(void *arg)
 {
@@ -145,16 +171,17 @@ static void *writer_main(void *arg)
             int n = r->n_writers;
             if (r->bytes[slot] < ((size_t)4 << 20)) n = 1; /* small blocks: not worth the threads */
             const size_t each = (r->bytes[slot] / (size_t)n + 4095) & ~(size_t)4095;
+            void *(*fn)(void *) = r->map ? copy_slice : write_slice;
             int used = 0;
             for (size_t at = 0; at < r->bytes[slot]; at += each, used++) {
-                part[used].fd = r->fd;
+                part[used].fd = r->map ? -1 : r->fd;
                 part[used].src = (const char *)r->host[slot] + at;
                 part[used].bytes = r->bytes[slot] - at < each ? r->bytes[slot] - at : each;
-                part[used].offset = r->offset + (int64_t)at;
+                part[used].offset = r->map ? (int64_t)(intptr_t)(r->map + r->offset + (int64_t)at) : r->offset + (int64_t)at;
                 part[used].failed = 0;
-                if (used > 0) pthread_create(&th[used], NULL, write_slice, &part[used]);
+                if (used > 0) pthread_create(&th[used], NULL, fn, &part[used]);
             }
-            if (used > 0) write_slice(&part[0]);
+            if (used > 0) fn(&part[0]);
             for (int i = 1; i < used; i++) pthread_join(th[i], NULL);
             for (int i = 0; i < used; i++)
                 if (part[i].failed) {
@@ -243,8 +270,10 @@ typedef struct {
     double ratio;
     void *d_rows, *d_peq, *d_q;
     void *stream[2], *d_out[2], *d_work[2];
-    void *ev_start[2], *ev_stop[2]; /* around the scoring launches of the block in flight on stream[s] */
+    void *ev_start[4], *ev_stop[4]; /* around the scoring launches of block n: index n & 3 (block n runs on stream[n & 1]) */
     double gpu_ms;                  /* GPU time this device spent scoring the current bucket */
+    double busy_ms;                 /* ... and over the whole run: the reference's cal time for this device */
+    int have_prev;                  /* ev_stop of the previous block of this bucket is valid */
     int delay;                      /* test knob BGSA_DEBUG_DEVICE_DELAY: every block is scored 1 + delay times */
     int64_t first, count;           /* slice of the current bucket, in reads */
 } device_t;
@@ -388,7 +417,7 @@ int main(int argc, char **argv)
         }
     }
 
-    double total_start = now(), mem_time = 0, cal_time = 0;
+    double total_start = now(), mem_time = 0, cal_time = 0, pipeline_time = 0;
     if (sc_given) algo = BGSA_ALGO_BITPAL;
     CK(bgsa_hip_select_algorithm(algo));
     if (sc_given) {
@@ -453,8 +482,10 @@ int main(int argc, char **argv)
             CK(bgsa_hip_stream_create(&v->stream[s]));
             CK(bgsa_hip_malloc(&v->d_out[s], (size_t)REF_BUCKET_COUNT * (size_t)cap * esz));
             CK(bgsa_hip_malloc(&v->d_work[s], work_bytes ? work_bytes : 8));
-            CK(bgsa_hip_event_create(&v->ev_start[s]));
-            CK(bgsa_hip_event_create(&v->ev_stop[s]));
+        }
+        for (int e = 0; e < 4; e++) {
+            CK(bgsa_hip_event_create(&v->ev_start[e]));
+            CK(bgsa_hip_event_create(&v->ev_stop[e]));
         }
         /* on the device's own stream, and complete before anything is launched (the streams do not
          * synchronise with the NULL stream) */
@@ -469,7 +500,23 @@ int main(int argc, char **argv)
     for (int i = 0; i < RING; i++) CK(bgsa_hip_malloc_host(&ring.host[i], block_bytes));
     ring.fd = open(file_result, O_CREAT | O_TRUNC | O_RDWR, 0644);
     if (ring.fd < 0) { printf("Error - can't open or create file: %s\n", file_result); exit(1); }
-    ring.n_writers = 1;
+    /* the file's final size: every (bucket, query) row of scores, the last bucket padded to whole groups */
+    int64_t result_bytes = 0;
+    for (int b = 0; b < bucket_num; b++) {
+        int64_t n = total_reads - (int64_t)b * per_bucket;
+        if (n > per_bucket) n = per_bucket;
+        n = (n + HIP_V_NUM - 1) / HIP_V_NUM * HIP_V_NUM;
+        result_bytes += n * ref_count * (int64_t)esz;
+    }
+    const char *wmode = getenv("BGSA_WRITER_MODE");
+    const int want_map = wmode && !strncmp(wmode, "mmap", 4);   /* "mmap", or "mmap+populate" */
+    g_populate = wmode && strstr(wmode, "populate") != NULL;
+    if (want_map && result_bytes > 0 && ftruncate(ring.fd, (off_t)result_bytes) == 0) {
+        void *m = mmap(NULL, (size_t)result_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, ring.fd, 0);
+        if (m != MAP_FAILED) ring.map = (char *)m;
+        else if (ftruncate(ring.fd, 0) != 0) { printf("Error - can't size the result file\n"); exit(1); }
+    }
+    ring.n_writers = ring.map ? 8 : 1;
     if (getenv("BGSA_WRITER_THREADS")) ring.n_writers = atoi(getenv("BGSA_WRITER_THREADS"));
     if (ring.n_writers < 1) ring.n_writers = 1;
     if (ring.n_writers > 16) ring.n_writers = 16;
@@ -547,12 +594,21 @@ int main(int argc, char **argv)
         for (int64_t ref_start = 0;; ref_start += REF_BUCKET_COUNT, issued++) {
             const int s = (int)(issued & 1);
             if (slot_of[s] >= 0) { /* the block issued two steps ago on this stream pair: finish and hand over */
+                /* block n = issued - 2 is complete on every device.  Its share of the device's scoring time is the part of
+                 * [start, stop] that lies behind the previous block's stop: the two streams of a device overlap (block n's
+                 * launches are queued while block n - 1 still runs), and time must not be counted twice. */
+                const int e = (int)((issued - 2) & 3), ep = (int)((issued - 3) & 3);
                 for (int d = 0; d < n_dev; d++) {
                     CK(bgsa_hip_set_device(dev[d].gpu));
                     CK(bgsa_hip_stream_synchronize(dev[d].stream[s]));
                     if (dev[d].count) {
-                        float ms = 0;
-                        CK(bgsa_hip_event_elapsed_ms(dev[d].ev_start[s], dev[d].ev_stop[s], &ms));
+                        float ms = 0, since_prev = 0;
+                        CK(bgsa_hip_event_elapsed_ms(dev[d].ev_start[e], dev[d].ev_stop[e], &ms));
+                        if (dev[d].have_prev) {
+                            CK(bgsa_hip_event_elapsed_ms(dev[d].ev_stop[ep], dev[d].ev_stop[e], &since_prev));
+                            if (since_prev < ms) ms = since_prev > 0 ? since_prev : 0;
+                        }
+                        dev[d].have_prev = 1;
                         dev[d].gpu_ms += ms;
                     }
                 }
@@ -574,12 +630,12 @@ int main(int argc, char **argv)
                 device_t *v = &dev[d];
                 if (!v->count) continue;
                 CK(bgsa_hip_set_device(v->gpu));
-                CK(bgsa_hip_event_record(v->ev_start[s], v->stream[s]));
+                CK(bgsa_hip_event_record(v->ev_start[issued & 3], v->stream[s]));
                 for (int rep = 0; rep <= v->delay; rep++)
                     CK(bgsa_hip_cal_align_score_dev(algo, (const char *)v->d_q, (const hip_read_t *)v->d_peq, v->d_out[s],
                                                     ref_len, read_len, v->count, (int)ref_start, (int)ref_end, word_num,
                                                     threshold, v->d_work[s], work_bytes, v->stream[s]));
-                CK(bgsa_hip_event_record(v->ev_stop[s], v->stream[s]));
+                CK(bgsa_hip_event_record(v->ev_stop[issued & 3], v->stream[s]));
                 /* device tiles one after another inside the block (cal_mic.c:535-536) */
                 CK(bgsa_hip_memcpy_d2h(dst + (size_t)nq * (size_t)v->first * esz, v->d_out[s],
                                        (size_t)nq * (size_t)v->count * esz, v->stream[s]));
@@ -587,7 +643,7 @@ int main(int argc, char **argv)
             slot_of[s] = slot;
             bytes_of[s] = (size_t)nq * (size_t)count * esz;
         }
-        cal_time += now() - t0 - stalled; /* time with scoring work in flight on the GPUs */
+        pipeline_time += now() - t0 - stalled; /* wall time with scoring work in flight on the GPUs (copies and the wait for the writer included) */
         subjects_done += count;
         for (int d = 0; d < n_dev; d++) { /* a damaged query stream is an error, not a wrong score (bgsa_hip.h) */
             CK(bgsa_hip_set_device(dev[d].gpu));
@@ -611,13 +667,23 @@ int main(int argc, char **argv)
                 printf("\n");
             }
         }
-        for (int d = 0; d < n_dev; d++) dev[d].gpu_ms = 0;
+        for (int d = 0; d < n_dev; d++) {
+            dev[d].busy_ms += dev[d].gpu_ms;
+            dev[d].gpu_ms = 0;
+            dev[d].have_prev = 0;
+        }
     }
+    for (int d = 0; d < n_dev; d++)   /* the devices work side by side: the slowest one's scoring time */
+        if (dev[d].busy_ms * 1e-3 > cal_time) cal_time = dev[d].busy_ms * 1e-3;
     pthread_mutex_lock(&ring.lock);
     ring.done = 1;
     pthread_cond_broadcast(&ring.cond);
     pthread_mutex_unlock(&ring.lock);
     pthread_join(writer, NULL);
+    if (ring.map) {
+        if (ring.offset != result_bytes) { printf("Error - the result file is %ld bytes, planned %ld\n", (long)ring.offset, (long)result_bytes); exit(1); }
+        munmap(ring.map, (size_t)result_bytes);
+    }
     close(ring.fd);
     fclose(finfo);
     fclose(fd);
@@ -633,6 +699,10 @@ int main(int argc, char **argv)
     printf("subject_len   is %d\n", read_len);
     printf("subject_count is %ld\n\n", (long)subjects_done);
     printf("gpu_count     is %d\n", n_dev);
+    /* cal = time spent scoring, as the reference measures it around its compute call only (cal_cpu.c:111-118; per device
+     * in the KNC backend, cal_mic.c:150-152): here the GPU time of the scoring launches of every block (HIP events on the
+     * block's stream; with several GPUs the slowest device's), copies and file I/O outside, as they are outside there. */
+    printf("pipeline_busy_time  is %.2fs\n", pipeline_time);
     printf("cal_total_times     is %.2fs\n", cal_time);
     printf("total time          is %.2fs\n", total);
     const double cells = 1.0 * ref_len * ref_count * read_len * subjects_done;
@@ -647,9 +717,9 @@ int main(int argc, char **argv)
         bgsa_hip_free(v->d_rows); bgsa_hip_free(v->d_peq); bgsa_hip_free(v->d_q);
         for (int s = 0; s < 2; s++) {
             bgsa_hip_stream_destroy(v->stream[s]);
-            bgsa_hip_event_destroy(v->ev_start[s]); bgsa_hip_event_destroy(v->ev_stop[s]);
             bgsa_hip_free(v->d_out[s]); bgsa_hip_free(v->d_work[s]);
         }
+        for (int e = 0; e < 4; e++) { bgsa_hip_event_destroy(v->ev_start[e]); bgsa_hip_event_destroy(v->ev_stop[e]); }
     }
     free_mem(qbuf);
     free(info_name);

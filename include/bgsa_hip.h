@@ -305,6 +305,10 @@ int bgsa_hip_clock_probe_stop(double *mhz, int *xcc, int cap, int *n_out, double
  * Writes at most `cap` bytes to dst (may be NULL) and returns the stream length in bytes. */
 int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, unsigned char *dst, int cap);
 
+/* Queries a wave scores per load of its subject block in this thread's last scoring launch (0: none yet).  The launch's
+ * HBM traffic follows from it: ceil(queries / tile) x block bytes + the scores (bench.py: traffic_model). */
+int bgsa_hip_last_query_tile(void);
+
 /* Name of the kernel the previous call would launch for these shapes (for profiles/bench). */
 const char *bgsa_hip_kernel_name(int algo, int word_num);
 

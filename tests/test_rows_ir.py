@@ -13,8 +13,11 @@ import pytest
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "bgsa_amd" / "csrc"))
 import rows_ir as R  # noqa: E402
+import gen_rows_asm as G  # noqa: E402
 
 from conftest import load_golden  # noqa: E402
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _inputs(oracle, seed, nq, ns, qlen, slen):
@@ -344,10 +347,10 @@ def test_bitpal_set_generator_picks_widths_that_fit(tmp_path):
     import gen_rows_asm as G
     for scores in [(2, -3, -5), (5, -4, -10), (0, -1, -1)]:
         sc = R.BitpalScores(*scores)
-        plain, blocks = G.bitpal_widths(sc)
+        plain, blocks, _packed = G.bitpal_widths(sc)
         assert plain[0] == 1 and plain == list(range(1, plain[-1] + 1)) and plain[-1] <= 12 and blocks[-1] <= 8
         assert sc.planes * plain[-1] + 5 * plain[-1] + R.bitpal_body(plain[-1], sc).allocate_temps()[1] <= G.BITPAL_VGPR_BUDGET
-    assert G.bitpal_widths(R.BITPAL_DEFAULT) == (list(range(1, 12)), [5, 6, 7, 8])   # 352 bp in registers (2 waves/SIMD)
+    assert G.bitpal_widths(R.BITPAL_DEFAULT) == (list(range(1, 12)), [5, 6, 7, 8], False)   # 352 bp in registers (2 waves/SIMD)
 
 
 # ---- semi-global BitPAl (generator option -s): same row body, other first row and last-row maximum ----
@@ -384,3 +387,74 @@ def test_myers_peq_resident_column_blocks(oracle, qlen, slen, nwb):
     want = oracle.myers64(q, s)
     for i in range(q.shape[0]):
         assert np.array_equal(R.myers_blocked_simulate(s, q[i], nwb, peq_resident=True), want[i])
+
+
+# ---- the BitPAl generator over its whole stated domain (BitPAlGenerator.java:151-534 emits any integers) ----
+def _random_score_sets(seed, count, max_k):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        K = int(rng.integers(1, max_k + 1))
+        M = int(rng.integers(0, 13))
+        I = M - K
+        G = min(-1, I // 2) - int(rng.integers(0, 7))      # gap < 0 and mismatch >= 2 gap (make_plan normalises the rest)
+        if I >= 2 * G and G < 0:
+            out.append((M, I, G))
+    return out
+
+
+def test_bitpal_generator_random_score_sets_match_the_dp(oracle):
+    """240 random (match, mismatch, gap) with match - mismatch up to 30 — far beyond the five sets the library ships —
+    through the generator's row body on the IR interpreter, against linear-gap Needleman-Wunsch (and the semi-global DP
+    for every fourth set): one and two words, ragged lengths."""
+    for it, (M, I, G) in enumerate(_random_score_sets(2024, 240, 30)):
+        sc = R.BitpalScores(M, I, G)
+        nw = 1 + it % 2
+        rng = np.random.default_rng(it)
+        qlen, slen = int(rng.integers(6, 34)), int(rng.integers(32 * (nw - 1) + 1, 32 * nw + 1))
+        q = oracle.gen_reads(9000 + it, 1, qlen)
+        s = oracle.gen_reads(9500 + it, 10, slen)
+        if slen >= qlen:
+            s[:5, :qlen] = oracle.mutate(np.repeat(q, 5, axis=0), np.arange(5), it)      # related pairs: the value classes get used
+        semi = it % 4 == 3
+        body = R.bitpal_body(nw, sc)
+        st = R.bitpal_init_state(nw, s.shape[0], sc, semi)
+        R.run_rows(body, st, R.build_peq32(s, nw), q[0])
+        want = (oracle.dp_semiglobal if semi else oracle.dp_nw)(q, s, M, I, G)[0]
+        assert np.array_equal(R.bitpal_score(st, nw, qlen, slen, sc, semi), want), (M, I, G, nw, semi)
+
+
+@pytest.mark.parametrize("scores,nw_block,qlen,slen", [((10, -9, -15), 2, 70, 150), ((2, -3, -5), 2, 100, 150),
+                                                      ((16, -15, -16), 1, 40, 70), ((7, -12, -13), 2, 50, 100)])
+def test_bitpal_packed_carry_blocks_match_the_dp(oracle, scores, nw_block, qlen, slen):
+    """Column blocks with the carries of a row packed into ceil(chains / 32) words (make_blocked_packed): what lets score
+    sets with dozens of carry chains — 43 for 10/-9/-15, 67 for 16/-15/-16 — run at any subject length."""
+    sc = R.BitpalScores(*scores)
+    q = oracle.gen_reads(9700 + qlen, 2, qlen)
+    s = oracle.gen_reads(9800 + slen, 24, slen)
+    n = min(qlen, slen)
+    s[:12, :n] = oracle.mutate(q[np.arange(12) % 2][:, :n], np.arange(12), 5)
+    for semi in (False, True):
+        want = (oracle.dp_semiglobal if semi else oracle.dp_nw)(q, s, *scores)
+        for i in range(2):
+            assert np.array_equal(R.bitpal_packed_blocked_simulate(s, q[i], nw_block, sc, semi), want[i]), (scores, semi, i)
+    body, init, n_words = R.bitpal_packed_block_body(nw_block, sc)
+    assert n_words == (sc.chains + 31) // 32 and not any(init)
+
+
+def test_bitpal_generator_domain_is_stated_and_diagnosed(tmp_path):
+    """Where `any integers` ends: sets with many chains take the packed-carry column blocks; a set whose ONE-word row
+    body is over the register budget is refused with a message that names the quantity — by the generator and by
+    `make BITPAL_SETS=...` (gen_bitpal_sets.py exits 1), not with a traceback (round 2: max() of an empty sequence)."""
+    import subprocess
+    assert G.bitpal_widths(R.BitpalScores(5, -4, -10))[2] is False          # 22 chains: a register pair per chain still fits
+    for scores in ((10, -9, -15), (16, -15, -16)):     # two of the four sets round 2 crashed on
+        plain, blocks, packed = G.bitpal_widths(R.BitpalScores(*scores))
+        assert packed and plain and blocks
+    with pytest.raises(G.BitpalDomainError, match="match - mismatch = 150"):
+        G.bitpal_widths(R.BitpalScores(100, -50, -200))
+    gen = ROOT / "bgsa_amd" / "csrc" / "gen_bitpal_sets.py"
+    p = subprocess.run([sys.executable, str(gen), "--out", str(tmp_path), "100,-50,-200"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and "match - mismatch = 150" in p.stderr and "Traceback" not in p.stderr
+    p = subprocess.run([sys.executable, str(gen), "--out", str(tmp_path), "2,3,-5"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and "match > mismatch" in p.stderr and "Traceback" not in p.stderr
