@@ -403,7 +403,8 @@ def main() -> int:
     def probe_start(expected_s):
         if not use_probe:
             return False
-        return L.bgsa_hip_clock_probe_start(8, int(min(600000, max(2000, expected_s * 3e3 + 5000)))) == 0
+        return L.bgsa_hip_clock_probe_start(8, int(min(600000, max(2000, expected_s * 3e3 + 5000))),
+                                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
 
     def probe_stop():
         mhz, xcc = (ctypes.c_double * 16)(), (ctypes.c_int * 16)()
@@ -413,7 +414,7 @@ def main() -> int:
         per = sorted((int(xcc[i]), round(float(mhz[i]), 1)) for i in range(n.value))
         return {"sustained_mhz": round(float(np.mean([m for _, m in per])), 1), "nominal_mhz": 2400.0,
                 "per_probe_mhz": [m for _, m in per], "probe_xcc": [x for x, _ in per], "probe_seconds": round(secs.value, 3),
-                "method": "s_memtime / s_memrealtime deltas of sleeping one-wave workgroups (one per XCD, high-priority stream) "
+                "method": "s_memtime / s_memrealtime deltas of sleeping one-wave workgroups (one per XCD, a stream of their own) "
                           "that run beside the timed kernels from the opening fence to the closing one"}
 
     def timed(step_fn, steps, warmup, probe=False):
@@ -432,9 +433,16 @@ def main() -> int:
             ev0[i].record()
             step_fn()
             ev1[i].record()
+        if probing:
+            # the probes sleep on a stream of their own until told to stop: the closing fence's device-wide synchronize would
+            # wait for their time bound.  So: wait for the timed stream alone, release the probes (tens of microseconds),
+            # then the fence of the contract.
+            torch.cuda.current_stream(dev).synchronize()
+            clock_box[0] = probe_stop()
+        else:
+            clock_box[0] = None
         fence()
         elapsed = time.perf_counter() - t0
-        clock_box[0] = probe_stop() if probing else None
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -613,17 +613,16 @@ int banded_push_solid_offset()
 {
     static const int v = [] {
         const char *e = getenv("BGSA_BANDED_PUSH_SOLID");
-        const int x = e ? atoi(e) : 40;
-        return x >= 0 ? x : 40;
+        const int x = e ? atoi(e) : 32;
+        return x >= 0 ? x : 32;
     }();
     return v;
 }
 int banded_push_solid_margin()
 {
     static const int v = [] {
-        const char *e = getenv("BGSA_BANDED_SOLID_MARGIN");
-        const int x = e ? atoi(e) : 2;
-        return x >= 0 ? x : 2;
+        const char *e = getenv("BGSA_BANDED_SOLID_MARGIN");   // unset: (k + 2) / 2
+        return e ? atoi(e) : -1;
     }();
     return v;
 }
@@ -721,8 +720,10 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     const uint32_t push_max = static_cast<uint32_t>(banded_push_max());
     // one-word-window kernels: already from this row on if an alive lane is a solid survivor (gen_rows_asm.py: push_or)
     const uint32_t push_row_solid = std::min(push_row, static_cast<uint32_t>(k + banded_push_solid_offset()));
-    // a solid survivor: at most this many errors since row k (the limit is k + 1; default: two below it)
-    const int margin = banded_push_solid_margin();
+    // a solid survivor: at most this many errors since row k — by default about half the limit of k + 1 (swept on
+    // 10k x 1M, k = 8, scripts/r03_solid.sh: rows k + 16 ... k + 32 with margins 4 ... 6 all give 128-129 ms on the 1 %
+    // mix and 88 ms on random pairs; with margin 2 random stragglers pass for survivors: 107 ms from row k + 32)
+    const int margin = banded_push_solid_margin() >= 0 ? banded_push_solid_margin() : (k + 2) / 2;
     const uint32_t solid_limit = static_cast<uint32_t>(k + 1 > margin ? k + 1 - margin : 0);
     if (cut > 0 && G == 2)
         hipLaunchKernelGGL((banded_cut_kernel<2>), grid, dim3(256), 0, stream,

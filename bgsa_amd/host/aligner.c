@@ -53,8 +53,14 @@
 
 #define READ_BUCKET_SIZE 114857600LL /* original/BGSA_CPU/config.h:6 */
 #define REF_BUCKET_COUNT 100         /* original/BGSA_CPU/config.h:13 */
-#define RING 4
+#define RING 3
 #define MAX_DEV 16
+/* Query blocks per scoring launch.  The file holds, per read bucket, block after block of REF_BUCKET_COUNT queries — with one
+ * device that is simply the bucket's row-major [queries][reads], so several blocks can be scored by ONE launch and go down as one
+ * piece; with several devices every block is still written as device 0's tile, device 1's, ... (one copy per block and device).
+ * A launch of 100 queries x 760k subjects is 5.8 rounds of workgroups on the chip and its tail shows: per-block launches spent
+ * 1.19 s of GPU time on 10k x 1M where one launch takes 1.06 s; four blocks per launch: BGSA_LAUNCH_BLOCKS (1..16). */
+#define LAUNCH_BLOCKS_DEFAULT 4
 
 static double now(void)
 {
@@ -463,8 +469,14 @@ int main(int argc, char **argv)
     const int word_num = bgsa_hip_word_num(algo, ref_len, read_len, threshold);
     const int64_t max_reads = total_reads < per_bucket ? (total_reads + HIP_V_NUM - 1) / HIP_V_NUM * HIP_V_NUM : per_bucket;
     const size_t rows_bytes = (size_t)(max_reads * row);
-    const size_t block_bytes = (size_t)REF_BUCKET_COUNT * (size_t)max_reads * esz;
-    const size_t work_bytes = bgsa_hip_workspace_bytes(algo, ref_len, read_len, REF_BUCKET_COUNT);
+    int launch_blocks = LAUNCH_BLOCKS_DEFAULT;
+    if (getenv("BGSA_LAUNCH_BLOCKS")) launch_blocks = atoi(getenv("BGSA_LAUNCH_BLOCKS"));
+    if (launch_blocks < 1) launch_blocks = 1;
+    if (launch_blocks > 16) launch_blocks = 16;
+    while (launch_blocks > 1 && (int64_t)(launch_blocks - 1) * REF_BUCKET_COUNT >= ref_count) launch_blocks--;   /* few queries: no more than needed */
+    const int64_t launch_queries = (int64_t)REF_BUCKET_COUNT * launch_blocks;
+    const size_t block_bytes = (size_t)launch_queries * (size_t)max_reads * esz;
+    const size_t work_bytes = bgsa_hip_workspace_bytes(algo, ref_len, read_len, (int)launch_queries);
 
     /* the widest slice any device can be handed: sizes every per-device allocation once */
     plan_slices(dev, n_dev, max_reads / HIP_V_NUM);
@@ -480,7 +492,7 @@ int main(int argc, char **argv)
         CK(bgsa_hip_malloc(&v->d_q, (size_t)qsize + 8));
         for (int s = 0; s < 2; s++) {
             CK(bgsa_hip_stream_create(&v->stream[s]));
-            CK(bgsa_hip_malloc(&v->d_out[s], (size_t)REF_BUCKET_COUNT * (size_t)cap * esz));
+            CK(bgsa_hip_malloc(&v->d_out[s], (size_t)launch_queries * (size_t)cap * esz));
             CK(bgsa_hip_malloc(&v->d_work[s], work_bytes ? work_bytes : 8));
         }
         for (int e = 0; e < 4; e++) {
@@ -585,13 +597,13 @@ int main(int argc, char **argv)
             reading = 1;
         }
 
-        /* ---- query blocks of REF_BUCKET_COUNT (cal_cpu.c:363-401), two in flight per GPU ------ */
+        /* ---- query blocks of REF_BUCKET_COUNT (cal_cpu.c:363-401), launch_blocks of them per launch, two launches in flight per GPU */
         t0 = now();
         double stalled = 0;
         int slot_of[2] = {-1, -1};
         size_t bytes_of[2] = {0, 0};
         int64_t issued = 0;
-        for (int64_t ref_start = 0;; ref_start += REF_BUCKET_COUNT, issued++) {
+        for (int64_t ref_start = 0;; ref_start += launch_queries, issued++) {
             const int s = (int)(issued & 1);
             if (slot_of[s] >= 0) { /* the block issued two steps ago on this stream pair: finish and hand over */
                 /* block n = issued - 2 is complete on every device.  Its share of the device's scoring time is the part of
@@ -619,7 +631,7 @@ int main(int argc, char **argv)
                 if (slot_of[s ^ 1] < 0) break;
                 continue; /* one more turn drains the other stream pair */
             }
-            int64_t ref_end = ref_start + REF_BUCKET_COUNT;
+            int64_t ref_end = ref_start + launch_queries;
             if (ref_end > ref_count) ref_end = ref_count;
             const int64_t nq = ref_end - ref_start;
             double w0 = now();
@@ -636,9 +648,18 @@ int main(int argc, char **argv)
                                                     ref_len, read_len, v->count, (int)ref_start, (int)ref_end, word_num,
                                                     threshold, v->d_work[s], work_bytes, v->stream[s]));
                 CK(bgsa_hip_event_record(v->ev_stop[issued & 3], v->stream[s]));
-                /* device tiles one after another inside the block (cal_mic.c:535-536) */
-                CK(bgsa_hip_memcpy_d2h(dst + (size_t)nq * (size_t)v->first * esz, v->d_out[s],
-                                       (size_t)nq * (size_t)v->count * esz, v->stream[s]));
+                /* device tiles one after another inside every block of REF_BUCKET_COUNT queries (cal_mic.c:535-536); with one
+                 * device the blocks of a launch are one contiguous piece */
+                if (n_dev == 1) {
+                    CK(bgsa_hip_memcpy_d2h(dst, v->d_out[s], (size_t)nq * (size_t)v->count * esz, v->stream[s]));
+                } else {
+                    for (int64_t q0 = 0; q0 < nq; q0 += REF_BUCKET_COUNT) {
+                        const int64_t nb = nq - q0 < REF_BUCKET_COUNT ? nq - q0 : REF_BUCKET_COUNT;
+                        CK(bgsa_hip_memcpy_d2h(dst + (size_t)q0 * (size_t)count * esz + (size_t)nb * (size_t)v->first * esz,
+                                               (char *)v->d_out[s] + (size_t)q0 * (size_t)v->count * esz,
+                                               (size_t)nb * (size_t)v->count * esz, v->stream[s]));
+                    }
+                }
             }
             slot_of[s] = slot;
             bytes_of[s] = (size_t)nq * (size_t)count * esz;

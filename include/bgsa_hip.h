@@ -287,11 +287,13 @@ int bgsa_hip_stream_faults(int clear);
 int bgsa_hip_debug_inject_stream_fault(int kind);
 
 /* The sustained shader clock while other launches run (bench.py's `clock` object): n_probes one-wave workgroups
- * (8 cover the 8 XCDs) are started on a high-priority stream of the library's own and sleep, reading the shader-clock
+ * (8 cover the 8 XCDs) are started on a stream of the library's own and sleep, reading the shader-clock
  * and the constant reference-clock counters, until bgsa_hip_clock_probe_stop() or until max_ms have passed — they
- * never outlive that bound.  stop() returns per probe the clock in MHz over its lifetime and the XCD it ran on, and
+ * never outlive that bound.  caller_stream = the stream whose kernels are to be observed: start() picks a stream of its own
+ * on which the probes are SEEN to run beside that stream (HIP shares hardware queues between streams; probes on the caller's
+ * queue would hold its kernels back), or fails with BGSA_HIP_EUNSUPPORTED.  stop() returns per probe the clock in MHz over its lifetime and the XCD it ran on, and
  * the longest probe lifetime in seconds.  Measurement only: nothing in the scoring path depends on it. */
-int bgsa_hip_clock_probe_start(int n_probes, unsigned max_ms);
+int bgsa_hip_clock_probe_start(int n_probes, unsigned max_ms, void *caller_stream);
 int bgsa_hip_clock_probe_stop(double *mhz, int *xcc, int cap, int *n_out, double *seconds);
 
 /* Introspection (host only, no GPU): the packed code stream the kernels walk for one mapped query

@@ -21,6 +21,8 @@ here=$(pwd)
 echo "== reference host files on libbgsa_hip.so (align_hip seam from its OpenMP loop), -N $THREADS =="
 ( cd $D && t0=$(date +%s%N) && timeout -k 10 900 $here/$REFBIN -q query.txt -d subject.txt -f result_ref.txt -N $THREADS $REFARGS 2>&1 | grep -E "GCUPS|total time|cal_total|Error|bgsa_hip"; echo "wall $(( ($(date +%s%N) - t0) / 1000000 )) ms" )
 echo "== bgsa_amd/host/aligner (device-resident pipeline on the same C ABI) =="
-( cd $D && t0=$(date +%s%N) && timeout -k 10 900 $here/bgsa_amd/host/aligner -q query.txt -d subject.txt -f result_hip.txt $OURARGS 2>&1 | grep -E "GCUPS|total time|cal_total|Error|bgsa_hip"; echo "wall $(( ($(date +%s%N) - t0) / 1000000 )) ms" )
+( cd $D && t0=$(date +%s%N) && timeout -k 10 900 $here/bgsa_amd/host/aligner -q query.txt -d subject.txt -f result_hip.txt $OURARGS 2>&1 | grep -E "GCUPS|total time|cal_total|pipeline_busy|write_total|Error|bgsa_hip"; echo "wall $(( ($(date +%s%N) - t0) / 1000000 )) ms" )
 cmp $D/result_ref.txt $D/result_hip.txt && echo "result files identical"
+echo "== the same with the result sent to /dev/null: what the pipeline does when the sink keeps up (no file is kept: not a Total GCUPS) =="
+( cd $D && ln -s /dev/null sink.txt && timeout -k 10 900 $here/bgsa_amd/host/aligner -q query.txt -d subject.txt -f sink.txt $OURARGS 2>&1 | grep -E "GCUPS|total time|cal_total|pipeline_busy|write_total|Error" )
 rm -rf $D

@@ -1128,6 +1128,11 @@ for length, k in ((64, 8), (97, 12), (128, 4), (160, 15), (500, 8), (33, 3), (15
     sc[:64] = O.mutate(qc[np.arange(64) % 40], np.arange(64) % (2 * k + 6), 912)
     sc[64 * 3 + 5] = O.mutate(qc[7:8], [2], 913)[0]; sc[64 * 4 + 60] = O.mutate(qc[9:10], [k], 914)[0]   # lone survivors: regroup pass
     assert np.array_equal(B.align_all_pairs(qc, sc, algo=B.ALGO_BANDED, k=k), O.banded64(qc, sc, k)), ("banded", length, k)
+for length, k, groups in ((150, 8, 5), (70, 12, 1), (200, 4, 7)):   # an odd number of subject groups: the last wave of the two-groups-per-wave kernel holds one
+    qc = O.gen_reads(920 + length, 37, length); sc = O.gen_reads(921 + length, 64 * groups, length)
+    sc[:48] = O.mutate(qc[np.arange(48) % 37], np.arange(48) % (2 * k + 6), 922)
+    sc[-3] = O.mutate(qc[5:6], [1], 923)[0]                             # a lone survivor in the last group: regroup pass there too
+    assert np.array_equal(B.align_all_pairs(qc, sc, algo=B.ALGO_BANDED, k=k), O.banded64(qc, sc, k)), ("banded odd groups", length, k)
 for slen in (150, 700):   # semi-global Myers: asm kernels by default, the compiler-scheduled one under BGSA_MYERS_IMPL=c
     s = O.gen_reads(907 + slen, 70, slen)
     assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS, semi_global=True), O.dp_edit_semiglobal(q, s)), ("semi", slen)
@@ -1138,6 +1143,10 @@ print("knobs ok")
 @pytest.mark.parametrize("env", [{"BGSA_MYERS_IMPL": "c", "BGSA_BITPAL_IMPL": "c", "BGSA_BANDED_IMPL": "c"},
                                  {"BGSA_BANDED_IMPL": "s"},                                   # straight-line banded rows (LDS-selected words)
                                  {"BGSA_BANDED_IMPL": "p"},                                   # the band held in place for k <= 11 (re-anchor events)
+                                 {"BGSA_BANDED_IMPL": "a"},                                   # the funnel-shift row loop at every k (round 2's default)
+                                 {"BGSA_BANDED_GROUPS": "1"},                                 # one-word windows, one subject group per wave
+                                 {"BGSA_BANDED_PUSH_SOLID": "0", "BGSA_BANDED_SOLID_MARGIN": "0"},   # any lane within the limit counts as a solid survivor, from the first test
+                                 {"BGSA_BANDED_PUSH_SOLID": "48", "BGSA_BANDED_GROUPS": "2"},
                                  {"BGSA_BANDED_PUSH_MAX": "0"},                               # no survivor queue
                                  {"BGSA_BANDED_PUSH_MAX": "64", "BGSA_BANDED_PUSH_ROW": "0"},   # everything alive at the first test is queued
                                  {"BGSA_MYERS_MAX_PLAIN_WORDS": "8"},

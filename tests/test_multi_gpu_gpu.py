@@ -107,3 +107,25 @@ def test_bench_line_survives_a_gather_that_never_finishes():
     r = _bench_two_ranks({"BGSA_BENCH_GATHER_TIMEOUT": "0.001"}, ("--config", "2"), want_rc=3)
     assert r["n_gpus"] == 2 and r["value"] > 0
     assert "did not finish" in r["gather"]["error"] and r["gather_ok"] is False
+
+
+def test_bench_line_carries_the_sustained_clock_without_paying_for_it():
+    """N = 1: the clock probes (eight sleeping one-wave workgroups on a stream of the library's own) run beside the timed
+    kernels and are released BEFORE the closing device-wide synchronize — a first version left them to their time bound
+    and the line's wall time was 4.6 x the kernel time.  The line must carry a plausible clock per XCD and a wall time
+    per step that is the kernel time plus launch overhead."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--nq", "2000", "--ns", "256000",
+           "--no-cpu-baseline", "--no-total"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    c = r["clock"]
+    assert c is not None and len(c["per_probe_mhz"]) == 8 and sorted(c["probe_xcc"]) == list(range(8))
+    assert all(1000.0 < m < 2600.0 for m in c["per_probe_mhz"]), c
+    assert r["ms_per_step"] < 1.15 * r["roofline"]["kernel_ms"] + 2.0, (r["ms_per_step"], r["roofline"]["kernel_ms"])
+    assert c["probe_seconds"] < 2.0 * r["ms_per_step"] * 4 / 1e3 + 0.5
+    assert r["roofline"]["issued"]["frac_at_sustained_clock"] >= r["roofline"]["issued"]["frac"] * 0.99
+    assert r["ranks_seen"] == 1 and r["gather_ok"] is None and r["roofline"]["traffic_model"]["query_tile"] >= 1
