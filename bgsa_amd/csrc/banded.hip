@@ -368,19 +368,36 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
 // (one scalar unit per CU) would bound it, so two subject groups share a wave and every dispatch, shift counter and event
 // (G = 2, the default; BGSA_BANDED_GROUPS=1 is the A/B): groups 2w and 2w+1, rows interleaved instruction by instruction.
 // The wave stops when all 128 lanes are past the limit; the regroup list takes (query, group, lane).
-template <int G>
+template <int G, bool DYN = false>
 __global__ __launch_bounds__(256) void banded_cut_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
     unsigned *__restrict__ fault_word, const char *__restrict__ content, int ref_start, int len,
-    uint32_t push_row, uint32_t push_row_solid, uint32_t solid_limit, uint32_t push_max, uint32_t cut_rows)
+    uint32_t push_row, uint32_t push_row_solid, uint32_t solid_limit, uint32_t push_max, uint32_t cut_rows,
+    unsigned *__restrict__ task_counter)
 {
     __shared__ uint32_t s_regroup[kWavesPerBlock][kLanes];   // (query - q0) << 8 | group in wave << 6 | lane
     uint32_t *regroup = s_regroup[threadIdx.x >> 6];
-    int n_regroup = 0;   // wave-uniform
     const int lane = threadIdx.x & (kLanes - 1);
-    const int group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
-    if (group0 >= n_groups) return;
+    // DYN: the waves of a persistent grid take (wave-group, tile) tasks from a counter (bgsa_common.h "dynamic task handout")
+    const unsigned wave_groups = (static_cast<unsigned>(n_groups) + G - 1) / G;
+    const unsigned n_tasks = wave_groups * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
+    unsigned task = 0;
+    if constexpr (DYN) {
+        task = next_wave_task(task_counter);
+        if (task >= n_tasks) return;
+    }
+    do {
+    int group0, tile;
+    if constexpr (DYN) {
+        group0 = static_cast<int>((task % wave_groups) * G);
+        tile = static_cast<int>(task / wave_groups);
+    } else {
+        group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
+        tile = blockIdx.y;
+        if (group0 >= n_groups) return;
+    }
+    int n_regroup = 0;   // wave-uniform
     // an odd group count leaves the last wave's second half without a group: it runs the first one's again (loads only)
     const bool has[2] = {true, G == 2 && group0 + 1 < n_groups};
     const size_t group_words = static_cast<size_t>(kChars) * word_num * kLanes;
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
     const uint32_t band = static_cast<uint32_t>((1ull << (k + h + 1)) - 1ull);
     const uint32_t limit = static_cast<uint32_t>(h + 1);   // err > k+h+1  <=>  errors since row k > h+1
 
-    const int q0 = blockIdx.y * q_tile;
+    const int q0 = tile * q_tile;
     const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
     int8_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
 
@@ -479,6 +496,8 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
             dst[static_cast<size_t>(q) * ld + gg * kLanes] = result;
         }
     }
+    if constexpr (DYN) task = next_wave_task(task_counter);
+    } while (DYN && task < n_tasks);
 }
 
 // ---- regrouping of sparse survivors -------------------------------------------------------------------
@@ -653,6 +672,17 @@ int banded_impl()
     return impl;
 }
 
+// Dynamic task handout for the one-word-window kernels: BGSA_BANDED_DYNAMIC=1 (measurement knob; the loop's registers cost
+// the two-group kernel its fifth wave per SIMD).
+bool banded_dynamic_tasks()
+{
+    static const bool on = [] {
+        const char *e = getenv("BGSA_BANDED_DYNAMIC");
+        return e && e[0] == '1' && dynamic_tasks();
+    }();
+    return on;
+}
+
 // Subject groups per wave of the one-word-window kernel (BGSA_BANDED_GROUPS, 1 or 2; default 2).
 int banded_groups()
 {
@@ -725,16 +755,22 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     // mix and 88 ms on random pairs; with margin 2 random stragglers pass for survivors: 107 ms from row k + 32)
     const int margin = banded_push_solid_margin() >= 0 ? banded_push_solid_margin() : (k + 2) / 2;
     const uint32_t solid_limit = static_cast<uint32_t>(k + 1 > margin ? k + 1 - margin : 0);
-    if (cut > 0 && G == 2)
-        hipLaunchKernelGGL((banded_cut_kernel<2>), grid, dim3(256), 0, stream,
+    if (cut > 0) {
+        unsigned *counter = nullptr;
+        const long long blocks = static_cast<long long>(grid.x) * grid.y;
+        if (banded_dynamic_tasks() && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
+            counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
+            BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
+            grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
+        }
+        auto kernel = G == 2 ? (counter ? banded_cut_kernel<2, true> : banded_cut_kernel<2, false>)
+                             : (counter ? banded_cut_kernel<1, true> : banded_cut_kernel<1, false>);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
-                           fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut));
-    else if (cut > 0)
-        hipLaunchKernelGGL((banded_cut_kernel<1>), grid, dim3(256), 0, stream,
-                           static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
-                           static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
-                           fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut));
+                           fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut),
+                           counter);
+    }
     else if (phase > 0)
         hipLaunchKernelGGL((banded_asm_kernel<false, true>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,

@@ -295,6 +295,40 @@ __device__ __forceinline__ void dephase_persistent_workgroup()
     for (int i = 0; i < skew; i++) __builtin_amdgcn_s_sleep(8);             // ~512 cycles each
 }
 
+// ---- dynamic task handout for the register-resident kernels ------------------------------------------------------------
+// The chip's eight XCDs get the workgroups of a static grid round robin and do not sustain the same clock (bench.py's probe
+// waves: 2,216 to 2,305 MHz under the Myers kernel on one box), so with equal shares the slowest XCD finishes last.  With a
+// persistent grid whose WAVES take their (subject group, query tile) tasks from a device-wide counter every XCD takes work
+// at the rate it runs at: Myers 10k x 1M x 150 bp 218,300 -> 222,900 GCUPS, 64 bp 225,600 -> 232,000 (same box, round 3).
+// The counter sits behind the packed streams in the workspace (bgsa_hip_workspace_bytes reserves it) and is zeroed by a
+// memset node in front of the launch.  BGSA_DYNAMIC_TASKS=0 restores the static grids (A/B).
+inline bool dynamic_tasks()
+{
+    static const bool on = [] {
+        const char *e = getenv("BGSA_DYNAMIC_TASKS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// Workgroups of a persistent grid: every CU's wave slots (8 waves per SIMD = 8 workgroups of four waves per CU).
+inline int persistent_blocks()
+{
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * 8;
+    }();
+    return n;
+}
+// The counter of a launch whose streams take stream_bytes of the workspace.
+inline unsigned *task_counter_in(void *d_workspace, size_t stream_bytes)
+{
+    return reinterpret_cast<unsigned *>(static_cast<unsigned char *>(d_workspace) + ((stream_bytes + 255) & ~static_cast<size_t>(255)));
+}
+// Whether a launch of this many tasks may use the counter (32-bit task numbers).
+inline bool dynamic_tasks_fit(long long n_tasks) { return n_tasks > 0 && n_tasks < 0xffffffffll; }
+constexpr size_t kTaskCounterBytes = 512;   // what plan_workspace_bytes adds for it (alignment included)
+
 // Tasks of a column-block kernel are handed out from a device-wide counter (zeroed by the launcher, it
 // sits behind the carry buffers in the workspace): the XCDs do not sustain exactly the same clock, and with
 // a static round-robin the slowest one finished last (average occupancy 96 %; 800 bp: 239 -> 227 ms).
@@ -362,6 +396,11 @@ __device__ __forceinline__ void note_stream_fault(unsigned *fault_word, int left
 
 // ---- device helpers ---------------------------------------------------------------------------
 
+// The next task of this WAVE from a device-wide counter (wave-uniform result).  32-bit task numbers: the launchers keep the
+// static grid for the (hypothetical) launch with 2^32 tasks or more, and all of the index arithmetic stays unsigned — no
+// sign-extended 64-bit scalar near an asm block (scripts/check_asm_kernels.py looks for exactly that).
+__device__ __forceinline__ unsigned next_wave_task(unsigned *counter);
+
 // A wave-uniform byte string read through the scalar data cache, four characters per fetch.
 // Query rows have stride len+1 (reference cal_cpu.c:78), so a row may start at any byte
 // alignment: the fetch is the aligned dword pair that covers the next four bytes.  Everything
@@ -401,6 +440,13 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
     const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
     return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned next_wave_task(unsigned *counter)
+{
+    unsigned t = 0;
+    if ((threadIdx.x & (kLanes - 1)) == 0) t = atomicAdd(counter, 1u);
+    return __builtin_amdgcn_readfirstlane(t);
 }
 
 }  // namespace bgsa

@@ -55,47 +55,65 @@ __device__ __forceinline__ uint32_t bitpal_init_plane(int plane, int semi)
     return (semi && ((stored >> plane) & 1u)) ? ~0u : 0u;
 }
 
-template <int NW, bool SEMI>
+template <int NW, bool SEMI, bool DYN = false>
 __global__ __launch_bounds__(256) void bitpal_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word,
+    unsigned *__restrict__ task_counter)
 {
     constexpr int semi = SEMI;
     const int lane = threadIdx.x & (kLanes - 1);
-    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (group >= n_groups) return;
-
-    uint32_t P[kChars][NW];
-    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
-#pragma unroll
-    for (int c = 0; c < kChars; c++)
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-            P[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
-
-    const int q0 = blockIdx.y * q_tile;
-    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
-    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
-
-    for (int q = q0; q < q1; q++) {
-        uint32_t st[kBitpalPlanes * NW];
-#pragma unroll
-        for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);  // (:167-171)
-        const unsigned long long s =
-            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        note_stream_fault(fault_word, bitpal_rows_asm<NW>(st, P, uniform_u64(s),
-                                                          __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
-        int score;
-        if (semi) {
-            int run = kBitpalGap * ref_len;
-            score = run;
-            bitpal_last_row_max<NW>(st, 0, read_len, run, score);
-        } else {
-            score = kBitpalGap * (ref_len + read_len) + bitpal_column_sum<NW>(st, 0, read_len);
-        }
-        dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(score);
+    // DYN: the waves of a persistent grid take (group, tile) tasks from a counter (bgsa_common.h "dynamic task handout")
+    const unsigned n_tasks = static_cast<unsigned>(n_groups) * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
+    unsigned task = 0;
+    if constexpr (DYN) {
+        task = next_wave_task(task_counter);
+        if (task >= n_tasks) return;
     }
+    do {
+        int group, tile;
+        if constexpr (DYN) {
+            group = static_cast<int>(task % static_cast<unsigned>(n_groups));
+            tile = static_cast<int>(task / static_cast<unsigned>(n_groups));
+        } else {
+            group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+            tile = blockIdx.y;
+            if (group >= n_groups) return;
+        }
+
+        uint32_t P[kChars][NW];
+        const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+#pragma unroll
+        for (int c = 0; c < kChars; c++)
+#pragma unroll
+            for (int w = 0; w < NW; w++)
+                P[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+
+        const int q0 = tile * q_tile;
+        const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+        int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+        for (int q = q0; q < q1; q++) {
+            uint32_t st[kBitpalPlanes * NW];
+#pragma unroll
+            for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);  // (:167-171)
+            const unsigned long long s =
+                reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+            note_stream_fault(fault_word, bitpal_rows_asm<NW>(st, P, uniform_u64(s),
+                                                              __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
+            int score;
+            if (semi) {
+                int run = kBitpalGap * ref_len;
+                score = run;
+                bitpal_last_row_max<NW>(st, 0, read_len, run, score);
+            } else {
+                score = kBitpalGap * (ref_len + read_len) + bitpal_column_sum<NW>(st, 0, read_len);
+            }
+            dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(score);
+        }
+        if constexpr (DYN) task = next_wave_task(task_counter);
+    } while (DYN && task < n_tasks);
 }
 
 // Subjects wider than kBitpalMaxPlain words: column blocks of NW words, the carry chains of a row
@@ -353,11 +371,20 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
     if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
-    auto kernel = semi ? bitpal_asm_kernel<NW, true> : bitpal_asm_kernel<NW, false>;
+    // dynamic task handout where the loop's registers cost no occupancy (plain kernels of up to 8 words hold <= 5 waves' worth)
+    unsigned *counter = nullptr;
+    const long long blocks = static_cast<long long>(grid.x) * grid.y;
+    if (dynamic_tasks() && NW <= 8 && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
+        counter = task_counter_in(d_workspace, stream_stride(ref_len) * static_cast<size_t>(nq));
+        BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
+        grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
+    }
+    auto kernel = counter ? (semi ? bitpal_asm_kernel<NW, true, true> : bitpal_asm_kernel<NW, false, true>)
+                          : (semi ? bitpal_asm_kernel<NW, true, false> : bitpal_asm_kernel<NW, false, false>);
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
+                       nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault, counter);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

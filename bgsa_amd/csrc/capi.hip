@@ -225,8 +225,8 @@ static size_t plan_workspace_bytes(const Plan &plan, int ref_len, int read_len, 
         return blocked > in_memory ? blocked : in_memory;
     }
     if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k: sized for the worst k
-        return banded_stream_bound(ref_len) * n_queries;
-    return stream_stride(ref_len) * static_cast<size_t>(n_queries);
+        return banded_stream_bound(ref_len) * n_queries + kTaskCounterBytes;
+    return stream_stride(ref_len) * static_cast<size_t>(n_queries) + kTaskCounterBytes;   // bgsa_common.h "dynamic task handout"
 }
 
 }  // namespace bgsa

@@ -171,60 +171,83 @@ constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm 
 // five in-place row bodies selected by a scalar jump per row, every VALU instruction full rate
 // (the inter-word shifts are add-with-carry chains instead of v_alignbit_b32), query characters
 // from the packed code stream.  This is the kernel the launcher picks whenever NW <= 8.
-template <int NW, int G>
+template <int NW, int G, bool DYN = false>
 __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word,
+    unsigned *__restrict__ task_counter)
 {
     const int lane = threadIdx.x & (kLanes - 1);
-    const int group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
-    if (group0 >= n_groups) return;
-
-    uint32_t P[kChars][G * NW];
-#pragma unroll
-    for (int gi = 0; gi < G; gi++) {
-        const bool live = group0 + gi < n_groups;
-        const uint32_t *g = peq + static_cast<size_t>(group0 + gi) * kChars * word_num * kLanes + lane;
-#pragma unroll
-        for (int c = 0; c < kChars; c++)
-#pragma unroll
-            for (int w = 0; w < NW; w++)
-                P[c][gi * NW + w] = (live && w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+    // Static mapping (DYN = false): workgroup (x, y) = (four wave-groups, query tile).  Dynamic (bgsa_common.h "dynamic task
+    // handout"; a separate instantiation, so that the static kernels keep their register counts: the loop costs 5-8 VGPRs,
+    // which the widest widths do not have): a persistent grid whose waves take (wave-group, tile) tasks, tile-major like the
+    // static order.
+    const unsigned wave_groups = (static_cast<unsigned>(n_groups) + G - 1) / G;
+    const unsigned n_tasks = wave_groups * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
+    auto next_task = [&]() -> unsigned { return next_wave_task(task_counter); };
+    unsigned task = 0;
+    if constexpr (DYN) {
+        task = next_task();
+        if (task >= n_tasks) return;
     }
-
-    const int q0 = blockIdx.y * q_tile;
-    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
-    int16_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
-
-    for (int q = q0; q < q1; q++) {
-        uint32_t st[2 * G * NW];  // {VP, VN} per word
-#pragma unroll
-        for (int w = 0; w < G * NW; w++) {
-            st[2 * w] = ~0u;
-            st[2 * w + 1] = 0u;
+    do {
+        int group0, tile;
+        if constexpr (DYN) {
+            group0 = static_cast<int>((task % wave_groups) * G);
+            tile = static_cast<int>(task / wave_groups);
+        } else {
+            group0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * G);
+            tile = blockIdx.y;
+            if (group0 >= n_groups) return;
         }
-        const unsigned long long s =
-            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        int left;
-        if constexpr (NW <= kPairMaxWords)  // short rows: two per stream token (launch_asm packs it so)
-            left = myers_pair_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
-        else
-            left = myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
-        note_stream_fault(fault_word, left);
+
+        uint32_t P[kChars][G * NW];
 #pragma unroll
         for (int gi = 0; gi < G; gi++) {
-            int score = ref_len;  // D[m][n] = m + sum over the n subject columns of (VP - VN)
+            const bool live = group0 + gi < n_groups;
+            const uint32_t *g = peq + static_cast<size_t>(group0 + gi) * kChars * word_num * kLanes + lane;
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-                const int rem = read_len - 32 * w;
-                const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-                score += __popc(st[2 * (gi * NW + w)] & m) - __popc(st[2 * (gi * NW + w) + 1] & m);
-            }
-            if (group0 + gi < n_groups)
-                dst[static_cast<size_t>(q) * ld + gi * kLanes] = static_cast<int16_t>(-score);
+            for (int c = 0; c < kChars; c++)
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    P[c][gi * NW + w] = (live && w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
         }
-    }
+
+        const int q0 = tile * q_tile;
+        const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+        int16_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
+
+        for (int q = q0; q < q1; q++) {
+            uint32_t st[2 * G * NW];  // {VP, VN} per word
+#pragma unroll
+            for (int w = 0; w < G * NW; w++) {
+                st[2 * w] = ~0u;
+                st[2 * w + 1] = 0u;
+            }
+            const unsigned long long s =
+                reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+            int left;
+            if constexpr (NW <= kPairMaxWords)  // short rows: two per stream token (launch_asm packs it so)
+                left = myers_pair_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+            else
+                left = myers_rows_asm<NW, G>(st, P, uniform_u64(s), __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2));
+            note_stream_fault(fault_word, left);
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) {
+                int score = ref_len;  // D[m][n] = m + sum over the n subject columns of (VP - VN)
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const int rem = read_len - 32 * w;
+                    const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                    score += __popc(st[2 * (gi * NW + w)] & m) - __popc(st[2 * (gi * NW + w) + 1] & m);
+                }
+                if (group0 + gi < n_groups)
+                    dst[static_cast<size_t>(q) * ld + gi * kLanes] = static_cast<int16_t>(-score);
+            }
+        }
+        if constexpr (DYN) task = next_task();
+    } while (DYN && task < n_tasks);
 }
 
 // ---- semi-global (the generator's -m 0 -s, MyersGenerator.java:56-223) -------------------------------------
@@ -303,52 +326,70 @@ __global__ __launch_bounds__(256) void myers_semi_asm_kernel(
 // character-code planes once per task (B0 = C|T, B1 = G|T, B2 = N) and the row body rebuilds the
 // match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 11 VALU per
 // word, 7*NW+1 registers, two waves per SIMD at NW = 32.
-template <int NW>
+template <int NW, bool DYN = false>
 __global__ __launch_bounds__(256) void myers_global_planes_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
-    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word)
+    int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word,
+    unsigned *__restrict__ task_counter)
 {
     const int lane = threadIdx.x & (kLanes - 1);
-    const int group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (group >= n_groups) return;
-
-    uint32_t Bp[3 * NW];
-    const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        uint32_t p[kChars];
-#pragma unroll
-        for (int c = 0; c < kChars; c++) p[c] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
-        Bp[3 * w + 0] = p[1] | p[3];
-        Bp[3 * w + 1] = p[2] | p[3];
-        Bp[3 * w + 2] = p[4];
+    // DYN: the waves of a persistent grid take (group, tile) tasks from a counter (bgsa_common.h "dynamic task handout")
+    const unsigned n_tasks = static_cast<unsigned>(n_groups) * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
+    unsigned task = 0;
+    if constexpr (DYN) {
+        task = next_wave_task(task_counter);
+        if (task >= n_tasks) return;
     }
+    do {
+        int group, tile;
+        if constexpr (DYN) {
+            group = static_cast<int>(task % static_cast<unsigned>(n_groups));
+            tile = static_cast<int>(task / static_cast<unsigned>(n_groups));
+        } else {
+            group = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+            tile = blockIdx.y;
+            if (group >= n_groups) return;
+        }
 
-    const int q0 = blockIdx.y * q_tile;
-    const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
-    int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
-
-    for (int q = q0; q < q1; q++) {
-        uint32_t st[2 * NW];
+        uint32_t Bp[3 * NW];
+        const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-            st[2 * w] = ~0u;
-            st[2 * w + 1] = 0u;
-        }
-        const unsigned long long s =
-            reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
-        note_stream_fault(fault_word, myers_planes_rows_asm<NW>(st, Bp, uniform_u64(s),
-                                                                __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
-        int score = ref_len;
+            uint32_t p[kChars];
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const int rem = read_len - 32 * w;
-            const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-            score += __popc(st[2 * w] & m) - __popc(st[2 * w + 1] & m);
+            for (int c = 0; c < kChars; c++) p[c] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+            Bp[3 * w + 0] = p[1] | p[3];
+            Bp[3 * w + 1] = p[2] | p[3];
+            Bp[3 * w + 2] = p[4];
         }
-        dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(-score);
-    }
+
+        const int q0 = tile * q_tile;
+        const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
+        int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+
+        for (int q = q0; q < q1; q++) {
+            uint32_t st[2 * NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                st[2 * w] = ~0u;
+                st[2 * w + 1] = 0u;
+            }
+            const unsigned long long s =
+                reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
+            note_stream_fault(fault_word, myers_planes_rows_asm<NW>(st, Bp, uniform_u64(s),
+                                                                    __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2)));
+            int score = ref_len;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int rem = read_len - 32 * w;
+                const uint32_t m = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                score += __popc(st[2 * w] & m) - __popc(st[2 * w + 1] & m);
+            }
+            dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(-score);
+        }
+        if constexpr (DYN) task = next_wave_task(task_counter);
+    } while (DYN && task < n_tasks);
 }
 
 // Semi-global for subjects of 769..1024 bp: the code planes right-aligned like the Peq planes of myers_semi_asm_kernel;
@@ -606,10 +647,27 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     const int stride = static_cast<int>(kPairs ? pair_stream_stride(ref_len) : stream_stride(ref_len));
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kPairs ? kPairRefill : kCodeRefill, kPairs ? -1 : 7, stream, &fault)) return rc;
-    hipLaunchKernelGGL((myers_global_asm_kernel<NW, G>), grid, dim3(256), 0, stream,
+    unsigned *counter = nullptr;
+    const long long blocks = static_cast<long long>(grid.x) * grid.y;
+    if (dynamic_tasks() && NW <= 8 && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
+        counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
+        BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
+        grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
+    }
+    if constexpr (NW <= 8) {   // the widths with registers to spare have a dynamic instantiation
+        if (counter) {
+            hipLaunchKernelGGL((myers_global_asm_kernel<NW, G, true>), grid, dim3(256), 0, stream,
+                               static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                               read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                               nq, q_tile, stride, fault, counter);
+            BGSA_HIP_TRY(hipGetLastError());
+            return BGSA_HIP_OK;
+        }
+    }
+    hipLaunchKernelGGL((myers_global_asm_kernel<NW, G, false>), grid, dim3(256), 0, stream,
                        static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                        read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                       nq, q_tile, stride, fault);
+                       nq, q_tile, stride, fault, counter);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -664,11 +722,19 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                            read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
                            nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
-    else
-        hipLaunchKernelGGL((myers_global_planes_kernel<NW>), grid, dim3(256), 0, stream,
+    else if (dynamic_tasks() && NW >= 26 && dynamic_tasks_fit(static_cast<long long>(grid.x) * grid.y * kWavesPerBlock)) {   // two waves per SIMD with or without the loop's registers; narrower A/B widths keep theirs
+        unsigned *counter = task_counter_in(d_workspace, stream_stride(ref_len) * static_cast<size_t>(nq));
+        BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
+        const long long blocks = static_cast<long long>(grid.x) * grid.y;
+        hipLaunchKernelGGL((myers_global_planes_kernel<NW, true>), dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks())),
+                           dim3(256), 0, stream, static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
+                           read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
+                           nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault, counter);
+    } else
+        hipLaunchKernelGGL((myers_global_planes_kernel<NW, false>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                            read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
-                           nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
+                           nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault, nullptr);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
