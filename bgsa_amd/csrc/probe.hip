@@ -64,6 +64,7 @@ extern "C" {
 // queue of the stream they are meant to observe do not run BESIDE its kernels, they hold them back until the probes' time
 // bound (first version of this file: wall time per step x 4.6 with unchanged kernel times).  So the probes are started on
 // one candidate stream after another until a marker on the CALLER's stream is seen to complete while they run.
+// (One probe set per process, started and stopped by one thread: measurement plumbing, not part of the scoring path.)
 int bgsa_hip_clock_probe_start(int n_probes, unsigned max_ms, void *caller_stream)
 {
     if (n_probes < 1 || n_probes > kProbeMax || max_ms < 1 || max_ms > 600000) {
@@ -116,7 +117,11 @@ int bgsa_hip_clock_probe_start(int n_probes, unsigned max_ms, void *caller_strea
         for (int spin = 0; spin < 400 && !concurrent; spin++) {   // up to ~80 ms
             const hipError_t q = hipEventQuery(g_probe.progress);
             if (q == hipSuccess) concurrent = true;
-            else if (q != hipErrorNotReady) { set_error("hipEventQuery", q, __FILE__, __LINE__); return BGSA_HIP_EHIP; }
+            else if (q != hipErrorNotReady) {
+                *static_cast<volatile unsigned *>(g_probe.h_stop) = 1u;   // do not leave probes behind an error
+                set_error("hipEventQuery", q, __FILE__, __LINE__);
+                return BGSA_HIP_EHIP;
+            }
             else usleep(200);
         }
         if (concurrent) {
