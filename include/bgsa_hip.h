@@ -249,7 +249,9 @@ int bgsa_hip_map_queries_dev(char *d_content, int64_t bytes, void *stream);
  * read_len characters: the queries re-packed into 8-byte-aligned code streams the kernels fetch
  * through the scalar cache, plus, for subjects too long for the register-resident kernels (Myers
  * > 1024 bp, BitPAl beyond the plain widths of the selected score set, > 352 bp for 2/-3/-5), the
- * per-wave carry words of the column-block kernels.  Depends on the selected score set. */
+ * per-wave carry words of the column-block kernels, plus the task counter of the launches whose waves
+ * take their (subject group, query tile) tasks from it.  Depends on the selected score set.  A workspace
+ * belongs to ONE launch at a time: launches that may overlap (two streams) need one each. */
 size_t bgsa_hip_workspace_bytes(int algo, int ref_len, int read_len, int n_queries);
 
 /* The hot path.  d_content = mapped query rows, stride ref_len+1 (reference cal_cpu.c:78);
