@@ -305,7 +305,8 @@ int bgsa_hip_clock_probe_stop(double *mhz, int *xcc, int cap, int *n_out, double
  * two-rows-per-token stream of the <= 64 bp kernels (codes as for banded below, without EVENT).
  * BGSA_ALGO_BANDED (threshold k): 0..24 = two rows of classes a, b as 5*a + b, 25..29 = one row,
  * 30 = END, 31 = REFILL, 63 = EVENT + argument byte (1 reset the error count, 2 advance the match
- * words, 4 test the limit, 8 latch the reject mask).
+ * words, 4 test the limit, 8 latch the reject mask, 16 re-anchor the band (BGSA_BANDED_IMPL=p only), 32 cut the next
+ * one-word window (the default kernels for k <= 12)).
  * Writes at most `cap` bytes to dst (may be NULL) and returns the stream length in bytes. */
 int bgsa_hip_query_stream(int algo, const char *mapped_row, int ref_len, int k, unsigned char *dst, int cap);
 
