@@ -109,7 +109,7 @@ def test_single_rank_needs_no_process_group(oracle):
 
 
 # ---- the streamed per-block gather (ScoreGatherStream): block i travels while block i+1 is scored ----------
-def _stream_worker(rank, world, port, layout, out_path):
+def _stream_worker(rank, world, port, layout, out_path, ns=333):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,7 +117,7 @@ def _stream_worker(rank, world, port, layout, out_path):
     import oracle as O
 
     q = O.gen_reads(21, 23, 150) if rank == 0 else None      # 23 queries in blocks of 5: a ragged last block
-    s = O.gen_reads(22, 333, 150)                            # 333 subjects: ragged last shard
+    s = O.gen_reads(22, ns, 150)                             # 333 subjects: ragged last shard
     sa = ShardedAligner(dist=dist, score_fn=lambda a, b: torch.from_numpy(O.myers64(a, b)))
     blocks, shards = sa.run_streamed(q, s, block_rows=5, layout=layout)
     if rank == 0:
@@ -126,15 +126,16 @@ def _stream_worker(rank, world, port, layout, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,layout", [(2, "device_blocks"), (2, "row_major"), (3, "device_blocks")])
-def test_streamed_gather_under_gloo(tmp_path, oracle, world, layout):
+@pytest.mark.parametrize("world,layout,ns", [(2, "device_blocks", 333), (2, "row_major", 333), (3, "device_blocks", 333),
+                                             (8, "device_blocks", 1500)])     # eight ranks: the shape of the driver's SCALE run
+def test_streamed_gather_under_gloo(tmp_path, oracle, world, layout, ns):
     out = tmp_path / "blocks.npy"
-    mp.spawn(_stream_worker, args=(world, _free_port(), layout, str(out)), nprocs=world, join=True)
+    mp.spawn(_stream_worker, args=(world, _free_port(), layout, str(out), ns), nprocs=world, join=True)
     got = np.load(out)
     q = oracle.gen_reads(21, 23, 150)
-    s = oracle.gen_reads(22, 333, 150)
+    s = oracle.gen_reads(22, ns, 150)
     want = oracle.myers64(q, s)
-    shards = plan_shards(333, world)
+    shards = plan_shards(ns, world)
     parts = []
     for lo in range(0, 23, 5):
         blk = want[lo:lo + 5]
