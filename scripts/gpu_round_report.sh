@@ -52,7 +52,7 @@ if has banded; then
   done
 fi
 if has ubench; then
-  ( cd scripts/ubench && ./valu_rate 8 2000 > ../../$out/ubench_valu_rate.txt 2>&1; ./body_rate 20000 > ../../$out/ubench_body_rate.txt 2>&1; ./bank_conflict 4 4000 > ../../$out/ubench_operand_cost.txt 2>&1 )
+  ( cd scripts/ubench && ./valu_rate 8 2000 > ../../$out/ubench_valu_rate.txt 2>&1; ./body_rate 20000 > ../../$out/ubench_body_rate.txt 2>&1; ./bank_conflict 4 4000 > ../../$out/ubench_operand_cost.txt 2>&1; [ -x ./banded_mix ] && ./banded_mix 3000 > ../../$out/ubench_banded_mix.txt 2>&1 )
   step bitpal_sets 400 bash scripts/bitpal_sets_bench.sh $tag > $out/bitpal_sets.log 2>&1; cp gpurun_out/bitpal_sets_$tag.jsonl $out/bitpal_sets.jsonl 2>/dev/null
 fi
 echo done | tee -a $out/summary.txt
