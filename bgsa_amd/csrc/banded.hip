@@ -189,8 +189,31 @@ __device__ __forceinline__ void banded_finish_pair(uint32_t entry, const uint32_
         x1[c] = gl[(c * word_num + 0) * kLanes];
         x2[c] = gl[(c * word_num + 1) * kLanes];
     }
+    // The lane's query characters, 32 rows at a time and one chunk ahead of the rows that use them: a byte load per row put a
+    // memory round trip into every row (round 2's form of this pass: ~600 cycles per row; 1 % dense survivors 128.5 -> 116.6 ms).
+    // A row is len + 1 bytes ('\n' included), rows lie back to back: a 4-byte load at offset o stays inside the row iff o + 4 <= len + 1.
+    auto load_chars = [&](int r0, uint32_t (&q)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int o = r0 + 4 * j;
+            uint32_t w = 0;
+            if (o + 4 <= len + 1) {
+                __builtin_memcpy(&w, qrow + o, 4);
+            } else {
+                for (int b = 0; b < 4; b++)
+                    if (o + b < len) w |= static_cast<uint32_t>(qrow[o + b]) << (8 * b);
+            }
+            q[j] = w;
+        }
+    };
+    uint32_t qnext[8];
+    load_chars(0, qnext);
     for (int r0 = 0; r0 < len; r0 += 32) {
         const int wi = r0 >> 5;
+        uint32_t qc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) qc[j] = qnext[j];
+        if (r0 + 32 < len) load_chars(r0 + 32, qnext);
 #pragma unroll
         for (int c = 0; c < kChars; c++) {
             x0[c] = x1[c];
@@ -198,20 +221,31 @@ __device__ __forceinline__ void banded_finish_pair(uint32_t entry, const uint32_
             x2[c] = (wi + 2 < word_num) ? gl[(c * word_num + wi + 2) * kLanes] : 0u;
         }
         const int rows = len - r0 < 32 ? len - r0 : 32;
-        for (int j = 0; j < rows; j++) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {       // unrolled over the chunk's eight character words: the word is a register, not a select
+        const uint32_t word = qc[jj];
+#pragma unroll 1
+        for (int jb = 0; jb < 4; jb++) {
+            const int j = 4 * jj + jb;
+            if (j >= rows) break;                // wave-uniform
             const int r = r0 + j;
-            uint32_t c = qrow[r];
+            uint32_t c = (word >> (8 * jb)) & 0xffu;
             c = c > 4u ? 0u : c;
-            const uint32_t a = c == 0 ? x0[0] : c == 1 ? x0[1] : c == 2 ? x0[2] : c == 3 ? x0[3] : x0[4];
-            const uint32_t b = c == 0 ? x1[0] : c == 1 ? x1[1] : c == 2 ? x1[2] : c == 3 ? x1[3] : x1[4];
-            T win = BandWord<uint32_t>::funnel(b, a, j);
-            if constexpr (W == 64) {
-                const uint32_t d = c == 0 ? x2[0] : c == 1 ? x2[1] : c == 2 ? x2[2] : c == 3 ? x2[3] : x2[4];
-                win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
+            // the lane's class picks its words: compare-and-select, no control flow (lanes hold different queries)
+            uint32_t a = x0[0], b = x1[0], d = x2[0];
+#pragma unroll
+            for (uint32_t cc = 1; cc < kChars; cc++) {
+                const bool is = c == cc;
+                a = is ? x0[cc] : a;
+                b = is ? x1[cc] : b;
+                if constexpr (W == 64) d = is ? x2[cc] : d;
             }
+            T win = BandWord<uint32_t>::funnel(b, a, j);
+            if constexpr (W == 64) win |= static_cast<T>(BandWord<uint32_t>::funnel(d, b, j)) << 32;
             if (r == k) acc = 0;
             band_row<T>(win & band_mask, vp, vn, acc);
             if (r + 1 == last_check) dead = static_cast<uint32_t>(k) + acc > max_err;
+        }
         }
     }
     int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
