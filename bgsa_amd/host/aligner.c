@@ -20,10 +20,11 @@
  *     (cal_cpu.c:459-475): "cal" = time spent scoring (GPU time of the scoring launches, the reference's
  *     cal_total_times around its compute call, cal_cpu.c:111-118), "Total" = wall.
  *
- * The subject bucket lives in HBM: rows are uploaded once, preprocessed on the GPU, and every
- * query block is one asynchronous launch; a writer thread drains finished score blocks to disk
- * from a ring of pinned buffers while the GPU works on the next block (the reference's
- * input/output pthreads, thread.c:35-171, reduced to the one that matters here).
+ * The subject bucket lives in HBM: rows are uploaded once, preprocessed on the GPU, every launch scores a
+ * few query blocks, and — whenever they fit — the scores of ALL queries against the bucket stay in HBM
+ * too: the launches are queued back to back, the copy-out runs block by block on a second stream, and a
+ * writer thread drains a ring of pinned buffers to disk (the reference's input/output pthreads,
+ * thread.c:35-171, reduced to the one that matters here).  The GPU never waits for the file.
  *
  * With -n > 1 every bucket is cut into one contiguous slice of subject groups per GPU (the KNC
  * backend's dispatch by ratio, BGSA_KNC/global.c:374-431, -R gives the ratios), each GPU scores
@@ -53,7 +54,7 @@
 
 #define READ_BUCKET_SIZE 114857600LL /* original/BGSA_CPU/config.h:6 */
 #define REF_BUCKET_COUNT 100         /* original/BGSA_CPU/config.h:13 */
-#define RING 3
+#define RING 4
 #define MAX_DEV 16
 /* Query blocks per scoring launch.  The file holds, per read bucket, block after block of REF_BUCKET_COUNT queries — with one
  * device that is simply the bucket's row-major [queries][reads], so several blocks can be scored by ONE launch and go down as one
@@ -102,6 +103,7 @@ typedef struct {
     size_t bytes[RING];
     int state[RING]; /* 0 free, 1 filled, 2 handed out and being filled */
     int head, tail, done;
+    int n_slots;      /* slots in use (<= RING) */
     int fd;           /* the result file; blocks are written at their own offsets by several threads at once */
     int64_t offset;   /* file offset of the next block */
     char *map;        /* the whole result file mapped MAP_SHARED (NULL: the pwrite() path) */
@@ -199,7 +201,7 @@ static void *writer_main(void *arg)
         r->seconds += now() - t0;
         pthread_mutex_lock(&r->lock);
         r->state[slot] = 0;
-        r->tail = (slot + 1) % RING;
+        r->tail = (slot + 1) % r->n_slots;
         pthread_cond_broadcast(&r->cond);
         pthread_mutex_unlock(&r->lock);
     }
@@ -211,7 +213,7 @@ static int ring_acquire(ring_t *r)
     while (r->state[r->head]) pthread_cond_wait(&r->cond, &r->lock);
     int slot = r->head;
     r->state[slot] = 2;
-    r->head = (slot + 1) % RING;
+    r->head = (slot + 1) % r->n_slots;
     pthread_mutex_unlock(&r->lock);
     return slot;
 }
@@ -280,6 +282,9 @@ typedef struct {
     double gpu_ms;                  /* GPU time this device spent scoring the current bucket */
     double busy_ms;                 /* ... and over the whole run: the reference's cal time for this device */
     int have_prev;                  /* ev_stop of the previous block of this bucket is valid */
+    void *d_all;                    /* resident mode: the scores of ALL queries against this device's slice of the bucket */
+    void **lev_start, **lev_stop;   /* resident mode: events around launch i of the bucket */
+    void *ev_copied[2];             /* resident mode: behind the copy-out of the piece in ring slot parity 0 / 1 */
     int delay;                      /* test knob BGSA_DEBUG_DEVICE_DELAY: every block is scored 1 + delay times */
     int64_t first, count;           /* slice of the current bucket, in reads */
 } device_t;
@@ -475,8 +480,24 @@ int main(int argc, char **argv)
     if (launch_blocks > 16) launch_blocks = 16;
     while (launch_blocks > 1 && (int64_t)(launch_blocks - 1) * REF_BUCKET_COUNT >= ref_count) launch_blocks--;   /* few queries: no more than needed */
     const int64_t launch_queries = (int64_t)REF_BUCKET_COUNT * launch_blocks;
-    const size_t block_bytes = (size_t)launch_queries * (size_t)max_reads * esz;
     const size_t work_bytes = bgsa_hip_workspace_bytes(algo, ref_len, read_len, (int)launch_queries);
+
+    /* Resident results (the default when they fit): the GPU scores ALL queries against the bucket into HBM at its own pace — the
+     * launches are queued back to back — and the copy-out and the writer drain behind on a second stream.  The kernels then never
+     * wait for a ring slot: with a 20 GB result on tmpfs the chunked pipeline left the GPU idle two thirds of the time, clocking
+     * down between launches (cal 1.21 s on 10k x 1M against 1.10 s with a sink that keeps up).  15 GB of int16 scores per
+     * 760k-subject bucket at 10k queries: what 288 GB of HBM is for.  BGSA_RESULT_RESIDENT=0, or a bucket whose scores exceed
+     * BGSA_RESULT_RESIDENT_GB (default 64) per device, keeps the two-launches-in-flight ring pipeline. */
+    const int64_t n_launch = (ref_count + launch_queries - 1) / launch_queries;
+    double resident_gb = 64.0;
+    if (getenv("BGSA_RESULT_RESIDENT_GB")) resident_gb = atof(getenv("BGSA_RESULT_RESIDENT_GB"));
+    int resident = !(getenv("BGSA_RESULT_RESIDENT") && getenv("BGSA_RESULT_RESIDENT")[0] == '0') &&
+                   (double)ref_count * (double)max_reads * (double)esz <= resident_gb * 1e9 && n_launch <= 65536;
+
+    /* what goes through a ring slot: a whole launch in the ring pipeline; one block of REF_BUCKET_COUNT queries in resident mode,
+     * where the copy-out is independent of the launches (less page-locked memory to set up: 4 x 152 MB instead of 3 x 609 MB) */
+    const int64_t slot_queries = resident ? REF_BUCKET_COUNT : launch_queries;
+    const size_t block_bytes = (size_t)slot_queries * (size_t)max_reads * esz;
 
     /* the widest slice any device can be handed: sizes every per-device allocation once */
     plan_slices(dev, n_dev, max_reads / HIP_V_NUM);
@@ -499,6 +520,16 @@ int main(int argc, char **argv)
             CK(bgsa_hip_event_create(&v->ev_start[e]));
             CK(bgsa_hip_event_create(&v->ev_stop[e]));
         }
+        if (resident) {
+            CK(bgsa_hip_malloc(&v->d_all, (size_t)ref_count * (size_t)cap * esz));
+            v->lev_start = (void **)calloc((size_t)n_launch, sizeof(void *));
+            v->lev_stop = (void **)calloc((size_t)n_launch, sizeof(void *));
+            for (int64_t i = 0; i < n_launch; i++) {
+                CK(bgsa_hip_event_create(&v->lev_start[i]));
+                CK(bgsa_hip_event_create(&v->lev_stop[i]));
+            }
+            for (int e = 0; e < 2; e++) CK(bgsa_hip_event_create(&v->ev_copied[e]));
+        }
         /* on the device's own stream, and complete before anything is launched (the streams do not
          * synchronise with the NULL stream) */
         CK(bgsa_hip_memcpy_h2d(v->d_q, qbuf, (size_t)qsize, v->stream[0]));
@@ -509,7 +540,8 @@ int main(int argc, char **argv)
     memset(&ring, 0, sizeof ring);
     pthread_mutex_init(&ring.lock, NULL);
     pthread_cond_init(&ring.cond, NULL);
-    for (int i = 0; i < RING; i++) CK(bgsa_hip_malloc_host(&ring.host[i], block_bytes));
+    ring.n_slots = resident ? 4 : 3;   /* one-block pieces: 4 x 152 MB; whole launches: 3 x 609 MB (10k x 1M) */
+    for (int i = 0; i < ring.n_slots; i++) CK(bgsa_hip_malloc_host(&ring.host[i], block_bytes));
     ring.fd = open(file_result, O_CREAT | O_TRUNC | O_RDWR, 0644);
     if (ring.fd < 0) { printf("Error - can't open or create file: %s\n", file_result); exit(1); }
     /* the file's final size: every (bucket, query) row of scores, the last bucket padded to whole groups */
@@ -597,13 +629,86 @@ int main(int argc, char **argv)
             reading = 1;
         }
 
+        if (resident) {
+            /* ---- every launch of the bucket queued at once on stream[0]; pieces copied out in order on stream[1] ---------- */
+            t0 = now();
+            for (int64_t i = 0; i < n_launch; i++) {
+                const int64_t ref_start = i * launch_queries;
+                int64_t ref_end = ref_start + launch_queries;
+                if (ref_end > ref_count) ref_end = ref_count;
+                for (int d = 0; d < n_dev; d++) {
+                    device_t *v = &dev[d];
+                    if (!v->count) continue;
+                    CK(bgsa_hip_set_device(v->gpu));
+                    CK(bgsa_hip_event_record(v->lev_start[i], v->stream[0]));
+                    for (int rep = 0; rep <= v->delay; rep++)
+                        CK(bgsa_hip_cal_align_score_dev(algo, (const char *)v->d_q, (const hip_read_t *)v->d_peq,
+                                                        (char *)v->d_all + (size_t)ref_start * (size_t)v->count * esz, ref_len, read_len,
+                                                        v->count, (int)ref_start, (int)ref_end, word_num, threshold, v->d_work[0],
+                                                        work_bytes, v->stream[0]));
+                    CK(bgsa_hip_event_record(v->lev_stop[i], v->stream[0]));
+                }
+            }
+            int pending_slot = -1;
+            size_t pending_bytes = 0;
+            const int64_t n_piece = (ref_count + slot_queries - 1) / slot_queries;
+            for (int64_t i = 0; i <= n_piece; i++) {
+                int slot = -1;
+                size_t bytes = 0;
+                if (i < n_piece) {
+                    const int64_t ref_start = i * slot_queries;
+                    int64_t ref_end = ref_start + slot_queries;
+                    if (ref_end > ref_count) ref_end = ref_count;
+                    const int64_t nq = ref_end - ref_start;
+                    const int64_t launch = ref_start / launch_queries;   /* the launch that scores this piece */
+                    slot = ring_acquire(&ring);
+                    char *dst = (char *)ring.host[slot];
+                    for (int d = 0; d < n_dev; d++) {
+                        device_t *v = &dev[d];
+                        if (!v->count) continue;
+                        CK(bgsa_hip_set_device(v->gpu));
+                        CK(bgsa_hip_stream_wait_event(v->stream[1], v->lev_stop[launch]));
+                        const char *src = (const char *)v->d_all + (size_t)ref_start * (size_t)v->count * esz;
+                        /* device tiles one after another inside the block (cal_mic.c:535-536) */
+                        CK(bgsa_hip_memcpy_d2h(dst + (size_t)nq * (size_t)v->first * esz, src, (size_t)nq * (size_t)v->count * esz, v->stream[1]));
+                        CK(bgsa_hip_event_record(v->ev_copied[i & 1], v->stream[1]));
+                    }
+                    bytes = (size_t)nq * (size_t)count * esz;
+                }
+                if (pending_slot >= 0) { /* the piece issued one step ago: its copies are done on every device -> to the writer */
+                    for (int d = 0; d < n_dev; d++) {
+                        if (!dev[d].count) continue;
+                        CK(bgsa_hip_set_device(dev[d].gpu));
+                        CK(bgsa_hip_event_synchronize(dev[d].ev_copied[(i - 1) & 1]));
+                    }
+                    ring_publish(&ring, pending_slot, pending_bytes);
+                }
+                pending_slot = slot;
+                pending_bytes = bytes;
+            }
+            /* the devices' scoring time: the union of the launches' intervals (they run back to back on one stream) */
+            for (int d = 0; d < n_dev; d++) {
+                if (!dev[d].count) continue;
+                CK(bgsa_hip_set_device(dev[d].gpu));
+                for (int64_t i = 0; i < n_launch; i++) {
+                    float ms = 0, since_prev = 0;
+                    CK(bgsa_hip_event_elapsed_ms(dev[d].lev_start[i], dev[d].lev_stop[i], &ms));
+                    if (i > 0) {
+                        CK(bgsa_hip_event_elapsed_ms(dev[d].lev_stop[i - 1], dev[d].lev_stop[i], &since_prev));
+                        if (since_prev < ms) ms = since_prev > 0 ? since_prev : 0;
+                    }
+                    dev[d].gpu_ms += ms;
+                }
+            }
+            pipeline_time += now() - t0;
+        }
         /* ---- query blocks of REF_BUCKET_COUNT (cal_cpu.c:363-401), launch_blocks of them per launch, two launches in flight per GPU */
         t0 = now();
         double stalled = 0;
         int slot_of[2] = {-1, -1};
         size_t bytes_of[2] = {0, 0};
         int64_t issued = 0;
-        for (int64_t ref_start = 0;; ref_start += launch_queries, issued++) {
+        for (int64_t ref_start = resident ? ref_count : 0;; ref_start += launch_queries, issued++) {
             const int s = (int)(issued & 1);
             if (slot_of[s] >= 0) { /* the block issued two steps ago on this stream pair: finish and hand over */
                 /* block n = issued - 2 is complete on every device.  Its share of the device's scoring time is the part of
@@ -664,7 +769,7 @@ int main(int argc, char **argv)
             slot_of[s] = slot;
             bytes_of[s] = (size_t)nq * (size_t)count * esz;
         }
-        pipeline_time += now() - t0 - stalled; /* wall time with scoring work in flight on the GPUs (copies and the wait for the writer included) */
+        if (!resident) pipeline_time += now() - t0 - stalled; /* wall time with scoring work in flight on the GPUs (copies and the wait for the writer included) */
         subjects_done += count;
         for (int d = 0; d < n_dev; d++) { /* a damaged query stream is an error, not a wrong score (bgsa_hip.h) */
             CK(bgsa_hip_set_device(dev[d].gpu));
@@ -730,7 +835,7 @@ int main(int argc, char **argv)
     printf("cal GCUPS is %.2f\n", cells / cal_time / 1e9);
     printf("Total GCUPS is %.2f\n\n\n", cells / total / 1e9);
 
-    for (int i = 0; i < RING; i++) bgsa_hip_free_host(ring.host[i]);
+    for (int i = 0; i < ring.n_slots; i++) bgsa_hip_free_host(ring.host[i]);
     bgsa_hip_free_host(h_rows);
     for (int d = 0; d < n_dev; d++) {
         device_t *v = &dev[d];
@@ -741,6 +846,12 @@ int main(int argc, char **argv)
             bgsa_hip_free(v->d_out[s]); bgsa_hip_free(v->d_work[s]);
         }
         for (int e = 0; e < 4; e++) { bgsa_hip_event_destroy(v->ev_start[e]); bgsa_hip_event_destroy(v->ev_stop[e]); }
+        if (resident) {
+            bgsa_hip_free(v->d_all);
+            for (int64_t i = 0; i < n_launch; i++) { bgsa_hip_event_destroy(v->lev_start[i]); bgsa_hip_event_destroy(v->lev_stop[i]); }
+            for (int e = 0; e < 2; e++) bgsa_hip_event_destroy(v->ev_copied[e]);
+            free(v->lev_start); free(v->lev_stop);
+        }
     }
     free_mem(qbuf);
     free(info_name);

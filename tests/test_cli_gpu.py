@@ -57,17 +57,20 @@ def test_cli_many_read_buckets_and_query_blocks(tmp_path, oracle):
     assert int(np.frombuffer(info[:4].tobytes(), dtype=np.int32)[0]) == 5
 
 
+@pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("launch_blocks,devices,mode", [("1", "0", None), ("4", "0", None), ("16", "0", None), ("4", "0,0,0", None),
                                                         ("3", "0,0", "mmap"), ("4", "0", "mmap+populate")])
-def test_cli_launch_blocks_and_writer_modes_give_the_same_file(tmp_path, oracle, launch_blocks, devices, mode):
+def test_cli_launch_blocks_and_writer_modes_give_the_same_file(tmp_path, oracle, launch_blocks, devices, mode, resident):
     """A launch scores BGSA_LAUNCH_BLOCKS query blocks of REF_BUCKET_COUNT at once; the file must not notice: with one device
     the blocks of a bucket are one contiguous piece, with several every block is still device 0's tile, device 1's, ...
     (cal_mic.c:535-536).  470 queries = four full blocks and a ragged fifth, two read buckets, the last one padded.  The same
-    with the alternative writers (the mapped file; measured slower on tmpfs, kept as BGSA_WRITER_MODE)."""
+    with the alternative writers (the mapped file; measured slower on tmpfs, kept as BGSA_WRITER_MODE), and with both pipelines:
+    the bucket's scores resident in HBM with the copy-out draining behind the kernels (the default), or two launches in flight
+    through the ring (BGSA_RESULT_RESIDENT=0)."""
     q = oracle.gen_reads(191, 470, 150)
     s = oracle.gen_reads(192, 700, 150)
     g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
-    env = {"BGSA_LAUNCH_BLOCKS": launch_blocks}
+    env = {"BGSA_LAUNCH_BLOCKS": launch_blocks, "BGSA_RESULT_RESIDENT": resident}
     if mode:
         env["BGSA_WRITER_MODE"] = mode
     got, report = _run_cli(tmp_path, g, bucket_bytes=448 * 151 + 10, extra_args=["-g", devices], env_extra=env)
