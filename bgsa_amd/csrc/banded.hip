@@ -261,6 +261,134 @@ __device__ __forceinline__ void banded_finish_pair(uint32_t entry, const uint32_
     out_tile[static_cast<size_t>(ql) * ld + sl] = result;
 }
 
+// The dense pass of the one-word-window kernels (k <= 12): the same pair-per-lane rescoring as banded_finish_pair with
+// every instruction of its row in the fast issue class — a half-rate-class instruction makes its whole row issue at the
+// slow rate, and banded_finish_pair's row holds a 64-bit shift, four v_cmp and eight v_cndmask.
+//   * windows as in the wave's own loop: per class the 32 bits of the match string cut every `cut` rows (five funnel shifts
+//     per cut, wave-uniform amount), the row shifts one word right by row mod cut;
+//   * the lane's class picks its word through three masks made of the class code's bits (0 - bit) and a four-deep tree of
+//     bitwise selects (v_bitop3) instead of compares and conditional moves;
+//   * characters that are no class (> 4) are cleared four at a time when the chunk is loaded (they score as class 0, as the
+//     stream packers have it), not compared per row.
+__device__ __forceinline__ uint32_t banded_clear_foreign_bytes(uint32_t w)
+{
+    // per byte: >= 5 (or >= 128) -> 0.  (b & 0x7f) + 123 carries into bit 7 iff (b & 0x7f) >= 5; no carry crosses a byte.
+    const uint32_t flag = (((w & 0x7f7f7f7fu) + 0x7b7b7b7bu) | w) & 0x80808080u;
+    const uint32_t ones = (flag - (flag >> 7)) | flag;   // 0xff where flagged
+    return w & ~ones;
+}
+
+// E[class of the lane], the class code in the low bits of `cs` (0..4), in twelve fast-class instructions.  Inline asm because
+// the compiler turns the same arithmetic back into v_bfe / v_cmp / v_cndmask / v_and_or — all half-rate class.
+// v_bitop3 0xd8: (a, b, c) -> c ? b : a.
+__device__ __forceinline__ uint32_t banded_pick_word(const uint32_t (&E)[kChars], uint32_t cs)
+{
+    uint32_t m0, m1, m2, t01, t23;
+    asm("v_and_b32 %0, 1, %5\n\t"
+        "v_lshrrev_b32 %1, 1, %5\n\t"
+        "v_lshrrev_b32 %2, 2, %5\n\t"
+        "v_sub_u32 %0, 0, %0\n\t"
+        "v_and_b32 %1, 1, %1\n\t"
+        "v_and_b32 %2, 1, %2\n\t"
+        "v_sub_u32 %1, 0, %1\n\t"
+        "v_sub_u32 %2, 0, %2\n\t"
+        "v_bitop3_b32 %3, %6, %7, %0 bitop3:0xd8\n\t"
+        "v_bitop3_b32 %4, %8, %9, %0 bitop3:0xd8\n\t"
+        "v_bitop3_b32 %3, %3, %4, %1 bitop3:0xd8\n\t"
+        "v_bitop3_b32 %3, %3, %10, %2 bitop3:0xd8"
+        : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(t01), "=&v"(t23)
+        : "v"(cs), "v"(E[0]), "v"(E[1]), "v"(E[2]), "v"(E[3]), "v"(E[4]));
+    return t01;
+}
+
+__device__ __forceinline__ void banded_finish_pair_cut(uint32_t entry, const uint32_t *__restrict__ g, const char *__restrict__ content,
+                                                       int first_query_row, int len, int word_num, int k, int cut,
+                                                       int8_t *__restrict__ out_tile, long long ld)
+{
+    const int ql = static_cast<int>(entry >> 8);
+    const uint32_t sl = entry & 63u;
+    const uint32_t *gl = g + sl;
+    const unsigned char *qrow = reinterpret_cast<const unsigned char *>(content) + static_cast<size_t>(first_query_row + ql) * (len + 1);
+    const int h = k;
+    const uint32_t band_mask = (1u << (k + h + 1)) - 1u;   // k <= 12: at most 25 bits
+    const uint32_t max_err = static_cast<uint32_t>(k + h + 1);
+    const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
+    uint32_t vp = 0, vn = 0, acc = 0;
+    bool dead = false;
+    uint32_t x0[kChars], x1[kChars], x2[kChars];
+#pragma unroll
+    for (int c = 0; c < kChars; c++) {
+        x0[c] = 0u;
+        x1[c] = gl[(c * word_num + 0) * kLanes];
+        x2[c] = gl[(c * word_num + 1) * kLanes];
+    }
+    auto load_chars = [&](int r0, uint32_t (&q)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int o = r0 + 4 * j;
+            uint32_t w = 0;
+            if (o + 4 <= len + 1) {
+                __builtin_memcpy(&w, qrow + o, 4);
+            } else {
+                for (int b = 0; b < 4; b++)
+                    if (o + b < len) w |= static_cast<uint32_t>(qrow[o + b]) << (8 * b);
+            }
+            q[j] = w;
+        }
+    };
+    uint32_t qnext[8];
+    load_chars(0, qnext);
+    for (int r0 = 0; r0 < len; r0 += 32) {
+        const int wi = r0 >> 5;
+        uint32_t qc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) qc[j] = banded_clear_foreign_bytes(qnext[j]);
+        if (r0 + 32 < len) load_chars(r0 + 32, qnext);
+#pragma unroll
+        for (int c = 0; c < kChars; c++) {
+            x0[c] = x1[c];
+            x1[c] = x2[c];
+            x2[c] = (wi + 2 < word_num) ? gl[(c * word_num + wi + 2) * kLanes] : 0u;
+        }
+        const int rows = len - r0 < 32 ? len - r0 : 32;
+        uint32_t E[kChars];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {       // unrolled over the chunk's eight character words
+            const int j0 = 4 * jj;
+            if (j0 >= rows) break;               // wave-uniform
+            if ((j0 & (cut - 1)) == 0) {         // a cut: cut is 16 or 8, so cuts fall on word boundaries of the characters
+#pragma unroll
+                for (int c = 0; c < kChars; c++) E[c] = BandWord<uint32_t>::funnel(x1[c], x0[c], j0);
+            }
+            const uint32_t word = qc[jj];
+#pragma unroll 1
+            for (int jb = 0; jb < 4; jb++) {
+                const int j = j0 + jb;
+                if (j >= rows) break;            // wave-uniform
+                const int r = r0 + j;
+                // the class code's three bits as masks (the characters are 0..4 here)
+                const uint32_t w = banded_pick_word(E, word >> (8 * jb)) >> (j & (cut - 1));
+                // rows k and last_check are wave-uniform events: real branches (the empty asm keeps the compiler from turning
+                // them into a compare and a conditional move in EVERY row)
+                if (r == k) { acc = 0; asm volatile("" : "+v"(acc)); }
+                band_row<uint32_t>(w & band_mask, vp, vn, acc);
+                if (r + 1 == last_check) { dead = static_cast<uint32_t>(k) + acc > max_err; asm volatile("" ::: "memory"); }
+            }
+        }
+    }
+    int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
+    if (!dead) {
+        uint32_t err = static_cast<uint32_t>(k) + acc, best = err;
+        for (int i = 0; i <= h; i++) {
+            err += (vp >> i) & 1u;
+            err -= (vn >> i) & 1u;
+            best = err < best ? err : best;
+        }
+        result = static_cast<int8_t>(best);
+    }
+    out_tile[static_cast<size_t>(ql) * ld + sl] = result;
+}
+
 // ---- generated row loop (gen_rows_asm.py: gen_banded_function) -----------------------------------
 #include "banded_rows_gen.inc"
 
@@ -464,8 +592,8 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
             if (lane < n_regroup) {
                 const uint32_t entry = regroup[lane];
                 const uint32_t gg = (entry >> 6) & 1u;
-                banded_finish_pair<uint32_t>(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num, k,
-                                             out + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes, ld);
+                banded_finish_pair_cut(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num, k, static_cast<int>(cut_rows),
+                                       out + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes, ld);
             }
             __builtin_amdgcn_wave_barrier();
             n_regroup = 0;
