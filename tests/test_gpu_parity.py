@@ -102,6 +102,44 @@ def test_banded_sparse_survivors_take_the_queue(oracle, k, length):
     assert (want != 127).sum() >= 20
 
 
+@pytest.mark.parametrize("k,length", [(8, 150), (12, 100), (15, 150), (31, 150)])
+def test_banded_foreign_query_bytes_score_as_class_0_in_every_pass(oracle, k, length):
+    """The device layer accepts any bytes in the mapped query buffer; a byte that is no class (> 4) scores as class 0 — in the
+    packed streams (bgsa_common.h: the packers clamp) and in the dense pass over regrouped survivors, which reads the query
+    rows itself (banded_finish_pair / banded_finish_pair_cut: foreign bytes are cleared four at a time when a chunk is
+    loaded).  Lone survivors in otherwise random groups force the dense pass; the same rows with zeros in those places must
+    score identically, and equal to the oracle on queries whose characters there are 'A'."""
+    import torch
+    nq = 9
+    q = oracle.gen_reads(7300 + k, nq, length)
+    s = oracle.gen_reads(7400 + k, 64 * 4, length)
+    for g, lane, qi in ((0, 5, 2), (1, 63, 7), (3, 0, 4), (2, 31, 2)):        # one or two near-duplicates per group of 64
+        s[64 * g + lane] = oracle.mutate(q[qi:qi + 1], [min(3, k - 1)], 7500 + g)[0]
+    a = B.DeviceAligner(B.ALGO_BANDED, k=k)
+    a.set_queries(q)
+    a.set_subjects(s)
+    rng = np.random.default_rng(k)
+    pos = rng.integers(0, length, (nq, 6))
+    content = a.d_content.cpu().numpy().copy()
+    zeroed = content.copy()
+    foreign = content.copy()
+    for i in range(nq):
+        for j, p in enumerate(pos[i]):
+            zeroed[i * (length + 1) + p] = 0
+            foreign[i * (length + 1) + p] = (5, 7, 9, 65, 200, 255)[j]
+    out = {}
+    for name, buf in (("zeroed", zeroed), ("foreign", foreign)):
+        a.d_content.copy_(torch.from_numpy(buf).to(a.d_content.device))
+        out[name] = a.score().cpu().numpy()[:, : s.shape[0]]
+        a.check_faults()
+    assert np.array_equal(out["foreign"], out["zeroed"])
+    qa = q.copy()
+    for i in range(nq):
+        qa[i, pos[i]] = ord("A")
+    assert np.array_equal(out["zeroed"], oracle.banded64(qa, s, k))
+    assert (out["zeroed"] != 127).sum() >= 3          # the planted pairs survive: the dense pass ran
+
+
 def test_banded_refuses_unequal_lengths(oracle):
     with pytest.raises(B.BgsaHipError):
         B.align_all_pairs(oracle.gen_reads(1, 2, 140), oracle.gen_reads(2, 64, 150), algo=B.ALGO_BANDED, k=8)
