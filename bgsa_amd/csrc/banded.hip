@@ -544,12 +544,13 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
     // DYN: the waves of a persistent grid take (wave-group, tile) tasks from a counter (bgsa_common.h "dynamic task handout")
     const unsigned wave_groups = (static_cast<unsigned>(n_groups) + G - 1) / G;
     const unsigned n_tasks = wave_groups * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
-    unsigned task = 0;
+    unsigned task = 0, task_issued = 0;
     if constexpr (DYN) {
-        task = next_wave_task(task_counter);
+        task = first_wave_task();
         if (task >= n_tasks) return;
     }
     do {
+    if constexpr (DYN) task_issued = issue_wave_task(task_counter);   // the next one, asked for under this one's work
     int group0, tile;
     if constexpr (DYN) {
         group0 = static_cast<int>((task % wave_groups) * G);
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
             dst[static_cast<size_t>(q) * ld + gg * kLanes] = result;
         }
     }
-    if constexpr (DYN) task = next_wave_task(task_counter);
+    if constexpr (DYN) task = resolve_wave_task(task_issued);
     } while (DYN && task < n_tasks);
 }
 
@@ -860,8 +861,7 @@ int launch_chunk(const char *d_content, const uint32_t *d_peq, int8_t *d_results
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    int q_tile = 32;
-    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    const int q_tile = pick_query_tile(nq, n_groups, len, 32);
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
@@ -887,15 +887,10 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    int q_tile = 32;
-    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
     const int phase = banded_stream_phase(k), cut = banded_stream_cut(k);
     const int G = cut > 0 ? banded_groups() : 1;
     const int64_t n_waves = (n_groups + G - 1) / G;
-    if (G == 2) {   // half as many waves per query tile: keep the grid as fine
-        q_tile = 32;
-        while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_waves + 3) / 4) < 4096) q_tile >>= 1;
-    }
+    const int q_tile = pick_query_tile(nq, n_waves, static_cast<long long>(len) * G, 32);
     if (int rc = launch_pack_banded(d_content, len, k, phase, cut, ref_start, ref_end, d_workspace, stream)) return rc;
     const int stride = banded_stream_layout(len, k, phase, cut, nullptr, nullptr);
     unsigned *fault = nullptr;
@@ -958,8 +953,7 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    int q_tile = 32;
-    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    const int q_tile = pick_query_tile(nq, n_groups, len, 32);
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));

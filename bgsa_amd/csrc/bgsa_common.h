@@ -60,8 +60,10 @@ __host__ __device__ inline unsigned long long plain_stream_window(const char *ro
     }
     return win;
 }
+// d_zero_word: a device word the packer also sets to 0 (the scoring launch's task counter: no memset
+// of its own between the two kernels), or null.
 int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
-                        void *d_streams, hipStream_t stream);
+                        void *d_streams, hipStream_t stream, unsigned *d_zero_word = nullptr);
 
 // Two-rows-per-token stream of the short-subject Myers kernels (<= 64 bp): token t covers query
 // characters 2t and 2t+1 as 5*a + b (0..24), an odd last character travels alone as 25 + c; 30 = END,
@@ -91,7 +93,7 @@ __host__ __device__ inline unsigned long long pair_stream_window(const char *row
     return win;
 }
 int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, int ref_end,
-                            void *d_streams, hipStream_t stream);
+                            void *d_streams, hipStream_t stream, unsigned *d_zero_word = nullptr);
 
 // Banded stream (rows_ir.py: banded_tokens / banded_stream_codes).  The banded row is short (12 VALU),
 // so the scalar work of the threaded-code dispatch is what its loop waits for; one token therefore
@@ -295,6 +297,34 @@ __device__ __forceinline__ void dephase_persistent_workgroup()
     for (int i = 0; i < skew; i++) __builtin_amdgcn_s_sleep(8);             // ~512 cycles each
 }
 
+// ---- queries per task --------------------------------------------------------------------------------------------------
+// A task is one wave's subject group(s) against `q_tile` consecutive queries: the Peq words are loaded once per task, so a
+// task needs enough rows to pay for that (row_words = subject columns x 32-bit words of one query's recurrence; 512 of
+// them are >= 6,000 instructions against ~100 of set-up).  The tile is halved from q_max until the launch has
+// BGSA_TASK_TARGET tasks (default 16,384 = two per wave slot of a 256-CU part).  Finer is not better: with 262,144 a
+// 12-query x 1M-subject x 150 bp launch (one tile of the coarse seam) went 1.43 -> 1.46 ms on the static grid, and to
+// 2.21 ms with the task counter (187,500 requests to one address in 1.4 ms); 100 queries 10.62 -> 10.79 ms static
+// (profiles/r03_seam_ab.txt).  A short launch loses its 5-10 % to start-up and drain, not to task size.
+inline long long task_target()
+{
+    static const long long n = [] {
+        const char *e = getenv("BGSA_TASK_TARGET");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? v : 16384ll;
+    }();
+    return n;
+}
+inline int pick_query_tile(int nq, long long wave_tasks_per_tile, long long row_words, int q_max,
+                           long long target = task_target(), long long min_words = 512)
+{
+    int q_min = 1;
+    while (q_min < q_max && q_min * row_words < min_words) q_min <<= 1;
+    int q_tile = q_max;
+    while (q_tile > q_min && ((nq + q_tile - 1) / q_tile) * wave_tasks_per_tile < target) q_tile >>= 1;
+    while (q_tile < q_max && (nq + q_tile - 1) / q_tile > 65535) q_tile <<= 1;   // the static grids put the tile in blockIdx.y
+    return q_tile;
+}
+
 // ---- dynamic task handout for the register-resident kernels ------------------------------------------------------------
 // The chip's eight XCDs get the workgroups of a static grid round robin and do not sustain the same clock (bench.py's probe
 // waves: 2,216 to 2,305 MHz under the Myers kernel on one box), so with equal shares the slowest XCD finishes last.  With a
@@ -326,7 +356,39 @@ inline unsigned *task_counter_in(void *d_workspace, size_t stream_bytes)
     return reinterpret_cast<unsigned *>(static_cast<unsigned char *>(d_workspace) + ((stream_bytes + 255) & ~static_cast<size_t>(255)));
 }
 // Whether a launch of this many tasks may use the counter (32-bit task numbers).
-inline bool dynamic_tasks_fit(long long n_tasks) { return n_tasks > 0 && n_tasks < 0xffffffffll; }
+// ... and only for launches long enough to gain from it: the counter costs a short launch a fixed 0.05-0.4 ms (150 bp x 1M
+// subjects, kernel ms static / dynamic: 12 queries 1.41 / 1.54, 25: 2.80 / 2.97, 100: 10.73 / 10.95, 400: 42.90 / 42.15 —
+// the crossover is between 8 and 25 tasks per wave slot), which is what made the coarse seam (12-query launches) slower.
+// Default floor: 16 tasks per wave of the persistent grid; BGSA_DYNAMIC_MIN_TASKS=<n> overrides (tests use 1).
+inline long long dynamic_min_tasks()
+{
+    static const long long n = [] {
+        const char *e = getenv("BGSA_DYNAMIC_MIN_TASKS");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? v : 16ll * persistent_blocks() * kWavesPerBlock;
+    }();
+    return n;
+}
+inline bool dynamic_tasks_fit(long long n_tasks) { return n_tasks >= dynamic_min_tasks() && n_tasks < 0xffffffffll; }
+// Queries per task and the handout of one launch.  With the counter a finer tile pays (100 / 200 / 400 queries x 1M x
+// 150 bp: 10.30 / 20.44 / 41.05 ms static, 10.21 / 20.30 / 40.68 with the counter and 262,144 tasks as the target), as long
+// as the requests stay rare: one address takes some tens of requests per microsecond from the whole chip (187,500 in a
+// 1.4 ms launch cost 0.8 ms), so a counter task is at least 3,000 row-words (~0.2 ms for a wave among eight on its SIMD).
+// BGSA_DYNAMIC_TASK_TARGET / BGSA_DYNAMIC_TASK_WORDS override the two numbers (tests, A/B).
+struct TaskPlan {
+    int q_tile;
+    bool dynamic;
+};
+inline TaskPlan plan_tasks(int nq, long long wave_tasks_per_tile, long long row_words, int q_max, bool counter_kernel)
+{
+    static const long long target = [] { const char *e = getenv("BGSA_DYNAMIC_TASK_TARGET"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 262144ll; }();
+    static const long long words = [] { const char *e = getenv("BGSA_DYNAMIC_TASK_WORDS"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 3000ll; }();
+    if (counter_kernel && dynamic_tasks()) {
+        const int q = pick_query_tile(nq, wave_tasks_per_tile, row_words, q_max, target, words);
+        if (dynamic_tasks_fit(((nq + q - 1) / q) * wave_tasks_per_tile)) return {q, true};
+    }
+    return {pick_query_tile(nq, wave_tasks_per_tile, row_words, q_max), false};
+}
 constexpr size_t kTaskCounterBytes = 512;   // what plan_workspace_bytes adds for it (alignment included)
 
 // Tasks of a column-block kernel are handed out from a device-wide counter (zeroed by the launcher, it
@@ -399,7 +461,9 @@ __device__ __forceinline__ void note_stream_fault(unsigned *fault_word, int left
 // The next task of this WAVE from a device-wide counter (wave-uniform result).  32-bit task numbers: the launchers keep the
 // static grid for the (hypothetical) launch with 2^32 tasks or more, and all of the index arithmetic stays unsigned — no
 // sign-extended 64-bit scalar near an asm block (scripts/check_asm_kernels.py looks for exactly that).
-__device__ __forceinline__ unsigned next_wave_task(unsigned *counter);
+__device__ __forceinline__ unsigned first_wave_task();
+__device__ __forceinline__ unsigned issue_wave_task(unsigned *counter);
+__device__ __forceinline__ unsigned resolve_wave_task(unsigned issued);
 
 // A wave-uniform byte string read through the scalar data cache, four characters per fetch.
 // Query rows have stride len+1 (reference cal_cpu.c:78), so a row may start at any byte
@@ -442,11 +506,25 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-__device__ __forceinline__ unsigned next_wave_task(unsigned *counter)
+// A wave's FIRST task is its own index in the persistent grid — no atomic: eight thousand waves asking one address at the
+// same instant take their turns at the L2 (measured through the coarse host seam, whose calls are eight small launches:
+// 11.8 ms per call with static grids, 12.5 with a counter fetch at the head of every wave's life).  The following tasks come
+// from the counter (it counts from 0: task = grid waves + value), and each is asked for BEFORE the current one is processed
+// (issue_wave_task ... resolve_wave_task), so the atomic's round trip runs under the task's work and the one request per
+// wave that finds nothing left is spread over the last tasks instead of arriving in a burst when the waves finish.
+__device__ __forceinline__ unsigned first_wave_task()
+{
+    return __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+}
+__device__ __forceinline__ unsigned issue_wave_task(unsigned *counter)
 {
     unsigned t = 0;
     if ((threadIdx.x & (kLanes - 1)) == 0) t = atomicAdd(counter, 1u);
-    return __builtin_amdgcn_readfirstlane(t);
+    return t;   // lane 0 holds it; resolve_wave_task() makes it wave-uniform when it is needed
+}
+__device__ __forceinline__ unsigned resolve_wave_task(unsigned issued)
+{
+    return __builtin_amdgcn_readfirstlane(issued) + gridDim.x * kWavesPerBlock;
 }
 
 }  // namespace bgsa

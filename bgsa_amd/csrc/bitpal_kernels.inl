@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
     const int lane = threadIdx.x & (kLanes - 1);
     // DYN: the waves of a persistent grid take (group, tile) tasks from a counter (bgsa_common.h "dynamic task handout")
     const unsigned n_tasks = static_cast<unsigned>(n_groups) * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
-    unsigned task = 0;
+    unsigned task = 0, task_issued = 0;
     if constexpr (DYN) {
-        task = next_wave_task(task_counter);
+        task = first_wave_task();
         if (task >= n_tasks) return;
     }
     do {
@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
         int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
 
         for (int q = q0; q < q1; q++) {
+            if constexpr (DYN) {   // the next task, asked for under this one's last query: late enough that the tail of a
+                if (q == q1 - 1) task_issued = issue_wave_task(task_counter);   // launch is handed out as waves free up, early enough that the round trip is hidden
+            }
             uint32_t st[kBitpalPlanes * NW];
 #pragma unroll
             for (int i = 0; i < kBitpalPlanes * NW; i++) st[i] = bitpal_init_plane(i % kBitpalPlanes, semi);  // (:167-171)
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
             }
             dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(score);
         }
-        if constexpr (DYN) task = next_wave_task(task_counter);
+        if constexpr (DYN) task = resolve_wave_task(task_issued);
     } while (DYN && task < n_tasks);
 }
 
@@ -346,12 +349,6 @@ int launch_blocks(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
     return BGSA_HIP_EUNSUPPORTED;
 }
 
-inline int pick_q_tile(int nq, int64_t n_groups)
-{
-    int q_tile = 16;
-    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
-    return q_tile;
-}
 
 template <int NW>
 int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
@@ -360,25 +357,26 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    const int q_tile = pick_q_tile(nq, n_groups);
+    // a BitPAl row is 2-4x a Myers row.  Counter where the loop's registers cost no occupancy (plain kernels of up to 8 words
+    // hold <= 5 waves' worth)
+    const TaskPlan plan = plan_tasks(nq, n_groups, static_cast<long long>(ref_len) * NW * 2, 16, NW <= 8);
+    const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
-    if (grid.y > 65535u) {
+    if (grid.y > 65535u && !plan.dynamic) {
         set_error_text("bitpal: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
-    unsigned *fault = nullptr;
-    if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
-    // dynamic task handout where the loop's registers cost no occupancy (plain kernels of up to 8 words hold <= 5 waves' worth)
-    unsigned *counter = nullptr;
-    const long long blocks = static_cast<long long>(grid.x) * grid.y;
-    if (dynamic_tasks() && NW <= 8 && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
+    unsigned *counter = nullptr;   // zeroed by the packer
+    if (plan.dynamic) {
+        const long long blocks = static_cast<long long>(grid.x) * grid.y;
         counter = task_counter_in(d_workspace, stream_stride(ref_len) * static_cast<size_t>(nq));
-        BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
         grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
     }
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)) return rc;
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
     auto kernel = counter ? (semi ? bitpal_asm_kernel<NW, true, true> : bitpal_asm_kernel<NW, false, true>)
                           : (semi ? bitpal_asm_kernel<NW, true, false> : bitpal_asm_kernel<NW, false, false>);
     hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream,

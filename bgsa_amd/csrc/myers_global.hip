@@ -185,10 +185,9 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
     // static order.
     const unsigned wave_groups = (static_cast<unsigned>(n_groups) + G - 1) / G;
     const unsigned n_tasks = wave_groups * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
-    auto next_task = [&]() -> unsigned { return next_wave_task(task_counter); };
-    unsigned task = 0;
+    unsigned task = 0, task_issued = 0;
     if constexpr (DYN) {
-        task = next_task();
+        task = first_wave_task();
         if (task >= n_tasks) return;
     }
     do {
@@ -219,6 +218,9 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
         int16_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
 
         for (int q = q0; q < q1; q++) {
+            if constexpr (DYN) {   // the next task, asked for under this one's last query: late enough that the tail of a
+                if (q == q1 - 1) task_issued = issue_wave_task(task_counter);   // launch is handed out as waves free up, early enough that the round trip is hidden
+            }
             uint32_t st[2 * G * NW];  // {VP, VN} per word
 #pragma unroll
             for (int w = 0; w < G * NW; w++) {
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void myers_global_asm_kernel(
                     dst[static_cast<size_t>(q) * ld + gi * kLanes] = static_cast<int16_t>(-score);
             }
         }
-        if constexpr (DYN) task = next_task();
+        if constexpr (DYN) task = resolve_wave_task(task_issued);
     } while (DYN && task < n_tasks);
 }
 
@@ -336,9 +338,9 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
     const int lane = threadIdx.x & (kLanes - 1);
     // DYN: the waves of a persistent grid take (group, tile) tasks from a counter (bgsa_common.h "dynamic task handout")
     const unsigned n_tasks = static_cast<unsigned>(n_groups) * ((static_cast<unsigned>(n_queries) + q_tile - 1) / q_tile);   // < 2^32: the launcher checked
-    unsigned task = 0;
+    unsigned task = 0, task_issued = 0;
     if constexpr (DYN) {
-        task = next_wave_task(task_counter);
+        task = first_wave_task();
         if (task >= n_tasks) return;
     }
     do {
@@ -369,6 +371,9 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
         int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
 
         for (int q = q0; q < q1; q++) {
+            if constexpr (DYN) {   // the next task, asked for under this one's last query: late enough that the tail of a
+                if (q == q1 - 1) task_issued = issue_wave_task(task_counter);   // launch is handed out as waves free up, early enough that the round trip is hidden
+            }
             uint32_t st[2 * NW];
 #pragma unroll
             for (int w = 0; w < NW; w++) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
             }
             dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(-score);
         }
-        if constexpr (DYN) task = next_wave_task(task_counter);
+        if constexpr (DYN) task = resolve_wave_task(task_issued);
     } while (DYN && task < n_tasks);
 }
 
@@ -598,11 +603,9 @@ int pick_nw(int word_num)
 // Queries per task.  Small enough that the grid has >> 256 CUs x 8 waves of tasks even for a
 // few thousand subjects, large enough that the 5*NW Peq loads are noise next to
 // q_tile * ref_len * 10 * NW VALU ops.
-int pick_q_tile(int nq, int64_t n_groups)
+int pick_q_tile(int nq, int64_t n_wave_tasks, int ref_len, int words)
 {
-    int q_tile = 32;
-    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
-    return q_tile;
+    return pick_query_tile(nq, n_wave_tasks, static_cast<long long>(ref_len) * words, 32);
 }
 
 // 0 = generated-asm row loop (default), 1 = compiler-scheduled C++ kernel (A/B and NW > 8).
@@ -632,28 +635,28 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    const int q_tile = pick_q_tile(nq, n_groups);
+    const TaskPlan plan = plan_tasks(nq, (n_groups + G - 1) / G, static_cast<long long>(ref_len) * NW * G, 32, NW <= 8);   // the widths with registers to spare have a counter instantiation
+    const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
-    if (grid.y > 65535u) {
+    if (grid.y > 65535u && !plan.dynamic) {
         set_error_text("myers: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
     constexpr bool kPairs = NW <= kPairMaxWords;
-    if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream)
-                        : launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream))
-        return rc;
     const int stride = static_cast<int>(kPairs ? pair_stream_stride(ref_len) : stream_stride(ref_len));
-    unsigned *fault = nullptr;
-    if (int rc = stream_guard(d_workspace, stride, kPairs ? kPairRefill : kCodeRefill, kPairs ? -1 : 7, stream, &fault)) return rc;
-    unsigned *counter = nullptr;
-    const long long blocks = static_cast<long long>(grid.x) * grid.y;
-    if (dynamic_tasks() && NW <= 8 && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
+    unsigned *counter = nullptr;   // the task counter behind the streams; the packer zeroes it
+    if (plan.dynamic) {
+        const long long blocks = static_cast<long long>(grid.x) * grid.y;
         counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
-        BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
         grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
     }
+    if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)
+                        : launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter))
+        return rc;
+    unsigned *fault = nullptr;
+    if (int rc = stream_guard(d_workspace, stride, kPairs ? kPairRefill : kCodeRefill, kPairs ? -1 : 7, stream, &fault)) return rc;
     if constexpr (NW <= 8) {   // the widths with registers to spare have a dynamic instantiation
         if (counter) {
             hipLaunchKernelGGL((myers_global_asm_kernel<NW, G, true>), grid, dim3(256), 0, stream,
@@ -679,7 +682,7 @@ int launch_semi_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_res
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    const int q_tile = pick_q_tile(nq, n_groups);
+    const int q_tile = pick_q_tile(nq, n_groups, ref_len, NW);
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
@@ -705,16 +708,20 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    int q_tile = 8;  // a task is already long: 8 queries x ref_len rows x 11*NW instructions
-    while (q_tile > 1 && ((nq + q_tile - 1) / q_tile) * ((n_groups + 3) / 4) < 4096) q_tile >>= 1;
+    // a task is already long: 8 queries x ref_len rows x 11*NW instructions.  Counter: two waves per SIMD with or without the
+    // loop's registers from 26 words up; narrower A/B widths keep theirs
+    const TaskPlan plan = plan_tasks(nq, n_groups, static_cast<long long>(ref_len) * NW, 8, !SEMI && NW >= 26);
+    const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));
-    if (grid.y > 65535u) {
+    const bool dynamic = plan.dynamic;
+    if (grid.y > 65535u && !dynamic) {
         set_error_text("myers: too many query tiles for one launch");
         return BGSA_HIP_EUNSUPPORTED;
     }
-    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream)) return rc;
+    unsigned *counter = dynamic ? task_counter_in(d_workspace, stream_stride(ref_len) * static_cast<size_t>(nq)) : nullptr;
+    if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)) return rc;
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, static_cast<int>(stream_stride(ref_len)), kCodeRefill, 7, stream, &fault)) return rc;
     if constexpr (SEMI)
@@ -722,9 +729,7 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                            read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
                            nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
-    else if (dynamic_tasks() && NW >= 26 && dynamic_tasks_fit(static_cast<long long>(grid.x) * grid.y * kWavesPerBlock)) {   // two waves per SIMD with or without the loop's registers; narrower A/B widths keep theirs
-        unsigned *counter = task_counter_in(d_workspace, stream_stride(ref_len) * static_cast<size_t>(nq));
-        BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
+    else if (dynamic) {
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
         hipLaunchKernelGGL((myers_global_planes_kernel<NW, true>), dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks())),
                            dim3(256), 0, stream, static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
@@ -818,7 +823,7 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    const int q_tile = pick_q_tile(nq, n_groups);
+    const int q_tile = pick_q_tile(nq, (n_groups + G - 1) / G, ref_len, NW * G);
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
               static_cast<unsigned>((nq + q_tile - 1) / q_tile));

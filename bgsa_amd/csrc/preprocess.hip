@@ -155,9 +155,10 @@ __global__ __launch_bounds__(256) void map_queries_kernel(char *content, long lo
 __global__ __launch_bounds__(256) void pack_queries_kernel(const char *__restrict__ content,
                                                            unsigned long long *__restrict__ streams,
                                                            int ref_len, int ref_start, int n_queries,
-                                                           int n_windows)
+                                                           int n_windows, unsigned *__restrict__ zero_word)
 {
     const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (zero_word && tid == 0) *zero_word = 0u;   // the scoring launch's task counter: zeroed here instead of by a memset of its own
     const int per = n_windows + 1;  // + the spare all-END window
     if (tid >= static_cast<long long>(n_queries) * per) return;
     const int q = static_cast<int>(tid / per), i = static_cast<int>(tid % per);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const char *__restric
 }
 
 int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int ref_end,
-                        void *d_streams, hipStream_t stream)
+                        void *d_streams, hipStream_t stream, unsigned *d_zero_word)
 {
     const int nq = ref_end - ref_start;
     if (nq <= 0) return BGSA_HIP_OK;
@@ -175,7 +176,7 @@ int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int r
     const long long total = static_cast<long long>(nq) * (n_windows + 1);
     hipLaunchKernelGGL(pack_queries_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
                        stream, d_content, static_cast<unsigned long long *>(d_streams), ref_len, ref_start,
-                       nq, n_windows);
+                       nq, n_windows, d_zero_word);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
@@ -183,9 +184,10 @@ int launch_pack_queries(const char *d_content, int ref_len, int ref_start, int r
 __global__ __launch_bounds__(256) void pack_query_pairs_kernel(const char *__restrict__ content,
                                                                unsigned long long *__restrict__ streams,
                                                                int ref_len, int ref_start, int n_queries,
-                                                               int n_windows)
+                                                               int n_windows, unsigned *__restrict__ zero_word)
 {
     const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (zero_word && tid == 0) *zero_word = 0u;   // as in pack_queries_kernel
     const int per = n_windows + 1;  // + the spare all-END window
     if (tid >= static_cast<long long>(n_queries) * per) return;
     const int q = static_cast<int>(tid / per), i = static_cast<int>(tid % per);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void pack_query_pairs_kernel(const char *__res
 }
 
 int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, int ref_end,
-                            void *d_streams, hipStream_t stream)
+                            void *d_streams, hipStream_t stream, unsigned *d_zero_word)
 {
     const int nq = ref_end - ref_start;
     if (nq <= 0) return BGSA_HIP_OK;
@@ -202,7 +204,7 @@ int launch_pack_query_pairs(const char *d_content, int ref_len, int ref_start, i
     const long long total = static_cast<long long>(nq) * (n_windows + 1);
     hipLaunchKernelGGL(pack_query_pairs_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
                        stream, d_content, static_cast<unsigned long long *>(d_streams), ref_len, ref_start,
-                       nq, n_windows);
+                       nq, n_windows, d_zero_word);
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }

@@ -1183,8 +1183,10 @@ print("knobs ok")
                                  {"BGSA_BANDED_IMPL": "p"},                                   # the band held in place for k <= 11 (re-anchor events)
                                  {"BGSA_BANDED_IMPL": "a"},                                   # the funnel-shift row loop at every k (round 2's default)
                                  {"BGSA_BANDED_GROUPS": "1"},                                 # one-word windows, one subject group per wave
-                                 {"BGSA_DYNAMIC_TASKS": "0"},                                 # static grids instead of the task counter
-                                 {"BGSA_BANDED_DYNAMIC": "1"},                                # ... and the banded kernel on the counter too
+                                 {"BGSA_DYNAMIC_TASKS": "0"},                                 # static grids at every launch size
+                                 {"BGSA_DYNAMIC_MIN_TASKS": "1"},                             # the task counter at every launch size (default: long launches only)
+                                 {"BGSA_DYNAMIC_MIN_TASKS": "1", "BGSA_DYNAMIC_TASK_WORDS": "1"},   # ... with one- and two-query tasks
+                                 {"BGSA_DYNAMIC_MIN_TASKS": "1", "BGSA_BANDED_DYNAMIC": "1"},     # ... and the banded kernel on the counter too
                                  {"BGSA_BANDED_PUSH_SOLID": "0", "BGSA_BANDED_SOLID_MARGIN": "0"},   # any lane within the limit counts as a solid survivor, from the first test
                                  {"BGSA_BANDED_PUSH_SOLID": "48", "BGSA_BANDED_GROUPS": "2"},
                                  {"BGSA_BANDED_PUSH_MAX": "0"},                               # no survivor queue
