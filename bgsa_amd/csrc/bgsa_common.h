@@ -330,8 +330,8 @@ inline int pick_query_tile(int nq, long long wave_tasks_per_tile, long long row_
 // waves: 2,216 to 2,305 MHz under the Myers kernel on one box), so with equal shares the slowest XCD finishes last.  With a
 // persistent grid whose WAVES take their (subject group, query tile) tasks from a device-wide counter every XCD takes work
 // at the rate it runs at: Myers 10k x 1M x 150 bp 218,300 -> 222,900 GCUPS, 64 bp 225,600 -> 232,000 (same box, round 3).
-// The counter sits behind the packed streams in the workspace (bgsa_hip_workspace_bytes reserves it) and is zeroed by a
-// memset node in front of the launch.  BGSA_DYNAMIC_TASKS=0 restores the static grids (A/B).
+// The counter sits behind the packed streams in the workspace (bgsa_hip_workspace_bytes reserves it) and is zeroed by the
+// query packer that runs in front of the launch (launch_pack_queries: d_zero_word).  BGSA_DYNAMIC_TASKS=0 restores the static grids (A/B).
 inline bool dynamic_tasks()
 {
     static const bool on = [] {
