@@ -129,3 +129,46 @@ def test_bench_line_carries_the_sustained_clock_without_paying_for_it():
     assert c["probe_seconds"] < 2.0 * r["ms_per_step"] * 4 / 1e3 + 0.5
     assert r["roofline"]["issued"]["frac_at_sustained_clock"] >= r["roofline"]["issued"]["frac"] * 0.99
     assert r["ranks_seen"] == 1 and r["gather_ok"] is None and r["roofline"]["traffic_model"]["query_tile"] >= 1
+
+
+def test_config5_eight_shards_one_after_another_equal_the_whole_bucket():
+    """BASELINE configs[4] (1k x 1M x 1000 bp) in its 8-GPU shape, on the one card there is: each of plan_shards(1M, 8)'s
+    subject slices is scored on its own, the way rank r would (own preprocess, own launch over 125k subjects: fewer
+    subject groups per query tile than the whole bucket's launch), and must equal the whole bucket's columns."""
+    import torch
+    import bgsa_amd as B
+    from bgsa_amd.multi_gpu import plan_shards
+    dev = torch.device("cuda:0")
+    nq, ns, length = 1000, 1_000_000, 1000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(55)
+    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    q_rows = letters[torch.randint(0, 4, (nq, length), generator=gen, device=dev)]
+    s_rows = torch.full((ns, length + 1), ord("\n"), dtype=torch.uint8, device=dev)
+    s_rows[:, :length] = letters[torch.randint(0, 4, (ns, length), generator=gen, device=dev)]
+    planted = torch.randperm(ns, generator=gen, device=dev)[:nq]
+    s_rows[planted, :length] = q_rows
+    q_host = q_rows.cpu().numpy()
+
+    whole = B.DeviceAligner(B.ALGO_MYERS, "cuda:0", 0)
+    whole.set_queries(q_host)
+    whole.set_subject_rows_device(s_rows.reshape(-1), ns, length, qlen=length)
+    ref = whole.score()
+    torch.cuda.synchronize()
+    assert bool((ref[torch.arange(nq, device=dev), planted] == 0).all())
+    tile_whole = B.lib().bgsa_hip_last_query_tile()
+
+    shards = plan_shards(ns, 8)
+    assert sum(s.count for s in shards) == ns and all(s.count % 64 == 0 for s in shards)
+    tiles = []
+    for sh in shards:
+        a = B.DeviceAligner(B.ALGO_MYERS, "cuda:0", 0)
+        a.set_queries(q_host)
+        a.set_subject_rows_device(s_rows[sh.start:sh.start + sh.count].reshape(-1), sh.count, length, qlen=length)
+        got = a.score()
+        torch.cuda.synchronize()
+        tiles.append(B.lib().bgsa_hip_last_query_tile())
+        assert torch.equal(got, ref[:, sh.start:sh.start + sh.count]), sh
+        del a, got
+    assert B.lib().bgsa_hip_stream_faults(1) == 0
+    print("query tile: whole bucket", tile_whole, "shards", tiles)
