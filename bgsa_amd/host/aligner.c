@@ -107,6 +107,8 @@ typedef struct {
     int fd;           /* the result file; blocks are written at their own offsets by several threads at once */
     int64_t offset;   /* file offset of the next block */
     char *map;        /* the whole result file mapped MAP_SHARED (NULL: the pwrite() path) */
+    int falloc;       /* BGSA_WRITER_MODE=mmap+falloc: a thread of its own allocates the file's pages ahead of the copies */
+    int64_t file_bytes, allocated;   /* ... the file's final size, and how far that thread has come (under `lock`) */
     int n_writers;
     double seconds;
     pthread_mutex_t lock;
@@ -123,7 +125,12 @@ typedef struct {
  * 5.08 / 4.57 / 5.02 / 5.51 s of writing with 1 / 4 / 8 / 16 threads against 3.51 s for the single pwrite() stream: a
  * page of a shared mapping arrives through a fault (about a microsecond each, five million of them), zeroed first, and
  * the faults of one file do not scale over threads either.  (`mmap+populate` faults each slice in with one
- * madvise(MADV_POPULATE_WRITE) instead.)  So the page cache of one tmpfs file takes about 6 GB/s whichever way the bytes
+ * madvise(MADV_POPULATE_WRITE) instead; `mmap+falloc` has a thread of its own fallocate() the file 256 MiB at a time ahead of
+ * the copies, so that they meet pages that exist: 5.18 / 4.65 / 2.75 / 3.57 s of writing with 1 / 4 / 8 / 16 copy threads and
+ * 3.95 s in total at best against 3.44-3.57 s for pwrite() on that box — a write fault per 4 KiB page of a shared mapping
+ * costs a microsecond even when the page is there.)  dd from /dev/zero into one /dev/shm file runs at 7.7-8.4 GB/s on these
+ * boxes and into 4 / 8 / 16 files at once at 30 / 52 / 72 GB/s (profiles/r03_writer.txt): tmpfs scales over files, not
+ * inside one.  So the page cache of one tmpfs file takes about 6 GB/s from a copying writer whichever way the bytes
  * arrive, and Total GCUPS of a 20 GB result stays near 60-70k while the kernels (cal) run at 200k+. */
 typedef struct {
     int fd;
@@ -160,6 +167,30 @@ static void *write_slice(void *arg)
     return NULL;
 }
 
+/* BGSA_WRITER_MODE=mmap+falloc: the pages of the result file are allocated by fallocate(), 256 MiB at a time, from a thread
+ * of its own that runs ahead of the copies (the file's size is known before the first block is scored); the copies then
+ * meet pages that exist and only have to map them.  fallocate() holds the inode lock like write(), but it does not copy. */
+static void *falloc_main(void *arg)
+{
+    ring_t *r = (ring_t *)arg;
+    const int64_t step = (int64_t)256 << 20;
+    for (int64_t at = 0; at < r->file_bytes; at += step) {
+        const int64_t len = r->file_bytes - at < step ? r->file_bytes - at : step;
+        if (fallocate(r->fd, 0, (off_t)at, (off_t)len) != 0) { /* not supported here: the copies fault their pages in themselves */
+            pthread_mutex_lock(&r->lock);
+            r->allocated = r->file_bytes;
+            pthread_cond_broadcast(&r->cond);
+            pthread_mutex_unlock(&r->lock);
+            return NULL;
+        }
+        pthread_mutex_lock(&r->lock);
+        r->allocated = at + len;
+        pthread_cond_broadcast(&r->cond);
+        pthread_mutex_unlock(&r->lock);
+    }
+    return NULL;
+}
+
 static void *writer_main(void *arg)
 {
     ring_t *r = (ring_t *)arg;
@@ -171,6 +202,8 @@ static void *writer_main(void *arg)
             return NULL;
         }
         int slot = r->tail;
+        if (r->falloc)   /* the block's pages first */
+            while (r->allocated < r->offset + (int64_t)r->bytes[slot] && r->allocated < r->file_bytes) pthread_cond_wait(&r->cond, &r->lock);
         pthread_mutex_unlock(&r->lock);
         double t0 = now();
         {
@@ -560,6 +593,12 @@ int main(int argc, char **argv)
         if (m != MAP_FAILED) ring.map = (char *)m;
         else if (ftruncate(ring.fd, 0) != 0) { printf("Error - can't size the result file\n"); exit(1); }
     }
+    pthread_t falloc_thread;
+    if (ring.map && wmode && strstr(wmode, "falloc") != NULL) {
+        ring.falloc = 1;
+        ring.file_bytes = result_bytes;
+        pthread_create(&falloc_thread, NULL, falloc_main, &ring);
+    }
     ring.n_writers = ring.map ? 8 : 1;
     if (getenv("BGSA_WRITER_THREADS")) ring.n_writers = atoi(getenv("BGSA_WRITER_THREADS"));
     if (ring.n_writers < 1) ring.n_writers = 1;
@@ -806,6 +845,7 @@ int main(int argc, char **argv)
     pthread_cond_broadcast(&ring.cond);
     pthread_mutex_unlock(&ring.lock);
     pthread_join(writer, NULL);
+    if (ring.falloc) pthread_join(falloc_thread, NULL);
     if (ring.map) {
         if (ring.offset != result_bytes) { printf("Error - the result file is %ld bytes, planned %ld\n", (long)ring.offset, (long)result_bytes); exit(1); }
         munmap(ring.map, (size_t)result_bytes);

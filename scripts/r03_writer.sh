@@ -28,6 +28,7 @@ for m in $MODES; do
   case $m in
     pwrite) run "pwrite, 1 stream (default)" BGSA_WRITER_MODE=pwrite;;
     mmap*) run "mmap, ${m#mmap} copy thread(s)" BGSA_WRITER_MODE=mmap BGSA_WRITER_THREADS=${m#mmap};;
+    falloc*) run "mmap + fallocate() ahead on a thread of its own, ${m#falloc} copy thread(s)" BGSA_WRITER_MODE=mmap+falloc BGSA_WRITER_THREADS=${m#falloc};;
     populate*) run "mmap + MADV_POPULATE_WRITE, ${m#populate} copy thread(s)" BGSA_WRITER_MODE=mmap+populate BGSA_WRITER_THREADS=${m#populate};;
   esac
 done

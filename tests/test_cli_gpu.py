@@ -59,7 +59,7 @@ def test_cli_many_read_buckets_and_query_blocks(tmp_path, oracle):
 
 @pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("launch_blocks,devices,mode", [("1", "0", None), ("4", "0", None), ("16", "0", None), ("4", "0,0,0", None),
-                                                        ("3", "0,0", "mmap"), ("4", "0", "mmap+populate")])
+                                                        ("3", "0,0", "mmap"), ("4", "0", "mmap+populate"), ("2", "0,0", "mmap+falloc")])
 def test_cli_launch_blocks_and_writer_modes_give_the_same_file(tmp_path, oracle, launch_blocks, devices, mode, resident):
     """A launch scores BGSA_LAUNCH_BLOCKS query blocks of REF_BUCKET_COUNT at once; the file must not notice: with one device
     the blocks of a bucket are one contiguous piece, with several every block is still device 0's tile, device 1's, ...
