@@ -922,7 +922,8 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
         }
         auto kernel = G == 2 ? (counter ? banded_cut_kernel<2, true> : banded_cut_kernel<2, false>)
                              : (counter ? banded_cut_kernel<1, true> : banded_cut_kernel<1, false>);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream,
+        static const unsigned lds_pad = [] { const char *e = getenv("BGSA_BANDED_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds_pad, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
                            fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut),
