@@ -315,52 +315,45 @@ __device__ __forceinline__ void banded_finish_pair_cut(uint32_t entry, const uin
     const int last_check = (len <= 64) ? len : ((len - h > 64) ? len - h : 64);
     uint32_t vp = 0, vn = 0, acc = 0;
     bool dead = false;
-    uint32_t x0[kChars], x1[kChars], x2[kChars];
+    uint32_t x0[kChars], x1[kChars];   // the two match-string words the chunk's 32 rows straddle
 #pragma unroll
     for (int c = 0; c < kChars; c++) {
         x0[c] = 0u;
         x1[c] = gl[(c * word_num + 0) * kLanes];
-        x2[c] = gl[(c * word_num + 1) * kLanes];
     }
-    auto load_chars = [&](int r0, uint32_t (&q)[8]) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int o = r0 + 4 * j;
-            uint32_t w = 0;
-            if (o + 4 <= len + 1) {
-                __builtin_memcpy(&w, qrow + o, 4);
-            } else {
-                for (int b = 0; b < 4; b++)
-                    if (o + b < len) w |= static_cast<uint32_t>(qrow[o + b]) << (8 * b);
-            }
-            q[j] = w;
+    // Four characters of the query row per load, the next four fetched while these are scored: two registers.  (Until the
+    // row loop went from 91 to 71 registers this pass held sixteen — the characters of 32 rows and of the next 32 — and was
+    // then what set the kernel's register count; it runs once per ~56 listed pairs, the row loop always.)
+    auto load_chars = [&](int o) {
+        uint32_t w = 0;
+        if (o + 4 <= len + 1) {
+            __builtin_memcpy(&w, qrow + o, 4);
+        } else {
+            for (int b = 0; b < 4; b++)
+                if (o + b < len) w |= static_cast<uint32_t>(qrow[o + b]) << (8 * b);
         }
+        return w;
     };
-    uint32_t qnext[8];
-    load_chars(0, qnext);
+    uint32_t qnext = load_chars(0);
     for (int r0 = 0; r0 < len; r0 += 32) {
         const int wi = r0 >> 5;
-        uint32_t qc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) qc[j] = banded_clear_foreign_bytes(qnext[j]);
-        if (r0 + 32 < len) load_chars(r0 + 32, qnext);
 #pragma unroll
         for (int c = 0; c < kChars; c++) {
             x0[c] = x1[c];
-            x1[c] = x2[c];
-            x2[c] = (wi + 2 < word_num) ? gl[(c * word_num + wi + 2) * kLanes] : 0u;
+            x1[c] = (wi + 1 < word_num) ? gl[(c * word_num + wi + 1) * kLanes] : 0u;
         }
         const int rows = len - r0 < 32 ? len - r0 : 32;
         uint32_t E[kChars];
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {       // unrolled over the chunk's eight character words
+#pragma unroll 1
+        for (int jj = 0; jj < 8; jj++) {       // the chunk's eight character words
             const int j0 = 4 * jj;
             if (j0 >= rows) break;               // wave-uniform
             if ((j0 & (cut - 1)) == 0) {         // a cut: cut is 16 or 8, so cuts fall on word boundaries of the characters
 #pragma unroll
                 for (int c = 0; c < kChars; c++) E[c] = BandWord<uint32_t>::funnel(x1[c], x0[c], j0);
             }
-            const uint32_t word = qc[jj];
+            const uint32_t word = banded_clear_foreign_bytes(qnext);
+            if (r0 + j0 + 4 < len) qnext = load_chars(r0 + j0 + 4);
 #pragma unroll 1
             for (int jb = 0; jb < 4; jb++) {
                 const int j = j0 + jb;
@@ -603,15 +596,14 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
         uint32_t st[3 * G];
 #pragma unroll
         for (int i = 0; i < 3 * G; i++) st[i] = 0u;
-        uint32_t M[G][kChars][4];
+        uint32_t M[G][kChars][2];
         uint32_t voff[G];
 #pragma unroll
         for (int gg = 0; gg < G; gg++) {
 #pragma unroll
             for (int c = 0; c < kChars; c++) {
-                M[gg][c][0] = first[gg][c][0];   // row 0: the first word itself
-                M[gg][c][1] = first[gg][c][0];
-                M[gg][c][2] = first[gg][c][1];
+                M[gg][c][0] = first[gg][c][0];   // the window of row 0: the first word itself
+                M[gg][c][1] = first[gg][c][1];   // the word behind it
             }
             voff[gg] = static_cast<uint32_t>(lane * 4 + 2 * kLanes * 4) + gstride[gg];   // word 2 of this lane
         }

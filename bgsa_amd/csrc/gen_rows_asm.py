@@ -556,11 +556,14 @@ def gen_banded_function(wide: bool, phase: bool = False) -> str:
 def gen_banded_cut_function(groups: int) -> str:
     """Row loop of the one-word-window banded kernel (k <= 12; rows_ir.banded_cut_body), for one or two subject
     groups per wave.  Same threaded-code skeleton, stream and events as gen_banded_function, plus EVENT bit 5 = cut.
-    Per group and class four registers: m0 = the cut word the rows shift (E), m1 / m2 = the 32-bit match-string words
-    the current 32 rows straddle (A, B), m3 = the next one, prefetched (C).  advance (bit 1, every 32 rows):
-    A <- B, B <- C, fetch C, E <- A; cut (bit 5, every `cutrows` rows in between): E <- ({B, A} >> rows since the
-    advance).  The row's shift count restarts at either.  With two groups the tests, the push decision and the early
-    exit look at both: the wave stops when all 128 lanes are past the limit."""
+    Per group and class TWO registers: m0 = the window the rows shift (A: at an advance the 32-bit match-string word the
+    next 32 rows start in), m1 = the word behind it (B).  advance (bit 1, every 32 rows): A <- B, fetch B (awaited by
+    the next cut, 16 or 8 rows later); cut (bit 5, every `cutrows` rows in between): A <- {B >> rows cut so far, A} >>
+    cutrows, i.e. the window moves up by cutrows bits in place.  The row's shift count restarts at either.  (Until
+    round 3's last change the loop kept four registers: the cut window apart from A, and the word after B prefetched a
+    whole advance ahead: 91 VGPRs = five waves per SIMD; two registers per class and group are 71 = seven.)
+    With two groups the tests, the push decision and the early exit look at both: the wave stops when all 128 lanes
+    are past the limit."""
     G = groups
     body = R.banded_cut_body(G)
     n_state = 3 * G
@@ -580,7 +583,7 @@ def gen_banded_cut_function(groups: int) -> str:
             if name.startswith("S"):
                 return f"%[s{name[1:]}]"
             if name.startswith("E"):
-                return f"%[m0_{c}_{name[1:]}]"
+                return f"%[m0_{c}_{name[1:]}]"       # the window: register A
             if name == "$mask":
                 return "%[vmask]"
             if name == "$sh":
@@ -677,11 +680,6 @@ def gen_banded_cut_function(groups: int) -> str:
     ]
     asm += [f"s_mov_b64 {S_DEAD[g]}, 0" for g in range(G)]
     asm += [f"s_mov_b64 {S_BASE[c]}, %[base{c}]" for c in range(5)]
-    # word 2 of every class is first needed after 32 rows: fetched here, awaited by the first advance event (ten registers
-    # less than keeping it across the queries of the tile)
-    for g in range(G):
-        asm += [f"global_load_dword %[m3_{c}_{g}], %[voff{g}], {S_BASE[c]}" for c in range(5)]
-    asm += [f"v_add_u32 %[voff{g}], 0x100, %[voff{g}]" for g in range(G)]
     asm += [
         f"s_getpc_b64 {S_PC}",
         "L_anchor_%=:",
@@ -783,28 +781,32 @@ def gen_banded_cut_function(groups: int) -> str:
         "s_cbranch_scc0 L_ev_cut_%=",
         "s_waitcnt vmcnt(0)",
     ]
-    for g in range(G):
-        for c in range(5):
-            asm += [f"v_mov_b32 %[m1_{c}_{g}], %[m2_{c}_{g}]", f"v_mov_b32 %[m2_{c}_{g}], %[m3_{c}_{g}]"]
-    for g in range(G):
-        for c in range(5):
-            asm.append(f"global_load_dword %[m3_{c}_{g}], %[voff{g}], {S_BASE[c]}")
-    asm += [f"v_add_u32 %[voff{g}], 0x100, %[voff{g}]" for g in range(G)]
-    for g in range(G):
+    for g in range(G):       # (vmcnt(0): a word fetched by the previous advance that no cut has waited for yet)
         asm += [f"v_mov_b32 %[m0_{c}_{g}], %[m1_{c}_{g}]" for c in range(5)]
+    for g in range(G):
+        for c in range(5):
+            asm.append(f"global_load_dword %[m1_{c}_{g}], %[voff{g}], {S_BASE[c]}")
+    asm += [f"v_add_u32 %[voff{g}], 0x100, %[voff{g}]" for g in range(G)]
     asm += [
         f"s_mov_b32 {S_SH}, 0",
         f"s_mov_b32 {S_CUT}, 0",
         f"s_add_u32 {S_CHUNK}, {S_CHUNK}, 1",
         "L_ev_cut_%=:",
-        f"s_bitcmp1_b32 {S_ARG}, 5",          # bit 5: the next one-word window of every class
+        f"s_bitcmp1_b32 {S_ARG}, 5",          # bit 5: the window of every class moves up by cutrows bits
         "s_cbranch_scc0 L_ev_out_%=",
-        f"s_add_u32 {S_CUT}, {S_CUT}, {S_CUTROWS}",
         f"s_mov_b32 {S_SH}, 0",
+        "s_waitcnt vmcnt(0)",                 # B, fetched by the last advance
+        f"s_cmp_eq_u32 {S_CUT}, 0",
+        "s_cbranch_scc0 L_ev_cut_again_%=",
     ]
-    for g in range(G):
-        asm += [f"v_alignbit_b32 %[m0_{c}_{g}], %[m2_{c}_{g}], %[m1_{c}_{g}], {S_CUT}" for c in range(5)]
-    asm += ["L_ev_out_%=:"]
+    for g in range(G):       # the first cut behind an advance: B's low bits follow A's
+        asm += [f"v_alignbit_b32 %[m0_{c}_{g}], %[m1_{c}_{g}], %[m0_{c}_{g}], {S_CUTROWS}" for c in range(5)]
+    asm += ["s_branch L_ev_cut_done_%=", "L_ev_cut_again_%=:"]
+    for g in range(G):       # a later one: the bits of B that earlier cuts took are gone first
+        for c in range(5):
+            asm += [f"v_lshrrev_b32 %[t0], {S_CUT}, %[m1_{c}_{g}]",
+                    f"v_alignbit_b32 %[m0_{c}_{g}], %[t0], %[m0_{c}_{g}], {S_CUTROWS}"]
+    asm += ["L_ev_cut_done_%=:", f"s_add_u32 {S_CUT}, {S_CUT}, {S_CUTROWS}", "L_ev_out_%=:"]
     asm += disp()
     asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")
     asm += [f"s_mov_b64 %[dead{g}], {S_DEAD[g]}" for g in range(G)]
@@ -812,7 +814,7 @@ def gen_banded_cut_function(groups: int) -> str:
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
-    outs += [f'[m{w}_{c}_{g}] "{"=&v" if w == 3 else "+v"}"(M[{g}][{c}][{w}])' for g in range(G) for c in range(5) for w in range(4)]
+    outs += [f'[m{w}_{c}_{g}] "+v"(M[{g}][{c}][{w}])' for g in range(G) for c in range(5) for w in range(2)]
     outs += [f'[voff{g}] "+v"(voff[{g}])' for g in range(G)]
     outs += [f'[dead{g}] "=s"(dead[{g}])' for g in range(G)]
     outs += ['[left] "=s"(left)', '[early] "=s"(early)']
@@ -824,13 +826,13 @@ def gen_banded_cut_function(groups: int) -> str:
     return f"""
 // One-word-window banded rows, {G} subject group{'s' if G > 1 else ''} per wave: {body.valu_count()} VALU per row, all fast class
 // ({sum(op.kind in ('alignbit',) for op in body.ops)} funnel shifts in the row; the cut event holds them), {n_slots} temporaries.
-// state[3g..3g+2] = {{VP, VN, errors since row k}} of group g; M[g][c] = {{cut word, word i, word i + 1, word i + 2 (prefetch
-// target, fetched by the loop itself: no input)}} of class c's offset match string; voff[g] = byte offset of word i + 2 relative
+// state[3g..3g+2] = {{VP, VN, errors since row k}} of group g; M[g][c] = {{window (in: word 0), the word behind it (in: word 1)}}
+// of class c's offset match string; voff[g] = byte offset of the next word to fetch (in: word 2) relative
 // to base[c] (group 1: the group stride included); dead[g] = reject mask of group g (lanes whose error count passed `limit` at the last
 // checkpoint, or all lanes if the wave stopped with every lane of every group past it); left / early as banded_rows_asm32
 // (early: the lanes NOT in dead[] go to the regroup list; from row push_row on whenever 1..push_max lanes are within the
 // limit, from row push_row_solid on if one of them has at most solid_limit errors since row k).
-__device__ __forceinline__ void banded_cut_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][4], uint32_t (&voff)[{G}],
+__device__ __forceinline__ void banded_cut_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][2], uint32_t (&voff)[{G}],
                                                        const unsigned long long (&base)[5],
                                                        const unsigned long long stream, const int n_windows,
                                                        const uint32_t band_mask, const uint32_t cut_rows,

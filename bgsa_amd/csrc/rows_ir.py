@@ -924,8 +924,9 @@ def banded_stream_bytes(length: int, k: int, codes, phase: int = 0, cut: int = 0
 
 def _banded_simulate_cut(subjects: np.ndarray, query: np.ndarray, k: int, cut: int, groups: int) -> np.ndarray:
     """banded_cut_kernel<G> on the CPU: banded_cut_body(groups) — the subjects split into `groups` halves that share
-    the token stream —, the cut / advance events as the generated loop runs them (E = ({B, A} >> cut offset) after an
-    advance or a cut; the row shifts E by the rows since), the final band walk."""
+    the token stream —, the cut / advance events as the generated loop runs them on its two registers per class (advance:
+    A <- B, B <- the next word; cut: A <- {B >> bits cut so far, A} >> cut; the row shifts A by the rows since), the
+    final band walk."""
     n, length = subjects.shape
     assert n % groups == 0
     code = np.zeros(256, dtype=np.uint8)
@@ -946,13 +947,11 @@ def _banded_simulate_cut(subjects: np.ndarray, query: np.ndarray, k: int, cut: i
     st = [np.zeros(per, dtype=np.uint32) for _ in range(3 * groups)]
     dead = np.zeros(n, dtype=bool)
     wi, sh, off = 0, 0, 0
-    E = [[mext[c, 0, sl[g]].copy() for c in range(5)] for g in range(groups)]   # row 0: the first word itself
+    E = [[mext[c, 0, sl[g]].copy() for c in range(5)] for g in range(groups)]   # register A; row 0: the first word itself
+    Bw = [[mext[c, 1, sl[g]].copy() for c in range(5)] for g in range(groups)]  # register B
 
-    def recut():
-        for g in range(groups):
-            for c in range(5):
-                pair = (mext[c, wi + 1, sl[g]].astype(np.uint64) << np.uint64(32)) | mext[c, wi, sl[g]].astype(np.uint64)
-                E[g][c] = ((pair >> np.uint64(off)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    def alignbit(hi, lo, s):
+        return ((((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> np.uint64(s)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
 
     qcode = code[query]
     stopped = False
@@ -970,10 +969,18 @@ def _banded_simulate_cut(subjects: np.ndarray, query: np.ndarray, k: int, cut: i
                     st[3 * g + 2] = np.zeros(per, dtype=np.uint32)
             if val & 2:
                 wi, sh, off = wi + 1, 0, 0
-                recut()
+                for g in range(groups):
+                    for c in range(5):
+                        E[g][c] = Bw[g][c]
+                        Bw[g][c] = mext[c, wi + 1, sl[g]].copy()
             if val & 32:
+                for g in range(groups):
+                    for c in range(5):
+                        E[g][c] = alignbit(Bw[g][c] >> np.uint32(off), E[g][c], cut)
                 off, sh = off + cut, 0
-                recut()
+                for g in range(groups):      # what the window must be: bits off.. of the 64-bit pair of this advance
+                    for c in range(5):
+                        assert np.array_equal(E[g][c], alignbit(mext[c, wi + 1, sl[g]], mext[c, wi, sl[g]], off))
         else:
             c = int(qcode[val])
             assert sh < cut and sh + 2 * k + 1 <= 32
