@@ -523,6 +523,9 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
 // (one scalar unit per CU) would bound it, so two subject groups share a wave and every dispatch, shift counter and event
 // (G = 2, the default; BGSA_BANDED_GROUPS=1 is the A/B): groups 2w and 2w+1, rows interleaved instruction by instruction.
 // The wave stops when all 128 lanes are past the limit; the regroup list takes (query, group, lane).
+// Registers: the loop lives on the waves a SIMD can choose from (4 -> 5 -> 6 waves: +6-11 %, +4-6 %), so the row
+// loop keeps two registers per class and group (gen_rows_asm.py: gen_banded_cut_function) and the dense pass is kept narrow:
+// 73 VGPRs = six waves per SIMD.
 template <int G, bool DYN = false>
 __global__ __launch_bounds__(256) void banded_cut_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
     const uint32_t *g = mext + static_cast<size_t>(group0) * group_words;
     const uint32_t gstride[2] = {0u, has[1] ? static_cast<uint32_t>(group_words * sizeof(uint32_t)) : 0u};
 
-    uint32_t first[G][kChars][2];   // words 0 and 1 stay across the tile's queries; word 2 is fetched by the row loop
+    uint32_t first[G][kChars][2];   // words 0 and 1 stay across the tile's queries; word 2 on is fetched by the row loop
     unsigned long long base[kChars];
 #pragma unroll
     for (int c = 0; c < kChars; c++) {

@@ -561,7 +561,7 @@ def gen_banded_cut_function(groups: int) -> str:
     the next cut, 16 or 8 rows later); cut (bit 5, every `cutrows` rows in between): A <- {B >> rows cut so far, A} >>
     cutrows, i.e. the window moves up by cutrows bits in place.  The row's shift count restarts at either.  (Until
     round 3's last change the loop kept four registers: the cut window apart from A, and the word after B prefetched a
-    whole advance ahead: 91 VGPRs = five waves per SIMD; two registers per class and group are 71 = seven.)
+    whole advance ahead: 91 VGPRs = five waves per SIMD; with two registers per class and group the kernel holds 73 = six.)
     With two groups the tests, the push decision and the early exit look at both: the wave stops when all 128 lanes
     are past the limit."""
     G = groups
