@@ -1174,6 +1174,21 @@ for length, k, groups in ((150, 8, 5), (70, 12, 1), (200, 4, 7)):   # an odd num
 for slen in (150, 700):   # semi-global Myers: asm kernels by default, the compiler-scheduled one under BGSA_MYERS_IMPL=c
     s = O.gen_reads(907 + slen, 70, slen)
     assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS, semi_global=True), O.dp_edit_semiglobal(q, s)), ("semi", slen)
+# a launch captured into a hipGraph and replayed twice: with the task counter the packer inside the graph zeroes it on every replay
+import torch
+for algo, want_fn in ((B.ALGO_MYERS, O.myers64), (B.ALGO_BITPAL, O.bitpal)):
+    qg = O.gen_reads(931, 70, 150); sg = O.gen_reads(932, 64 * 40, 150)
+    want = want_fn(qg, sg)
+    a = B.DeviceAligner(algo); a.set_queries(qg); a.set_subjects(sg)
+    outg = torch.zeros(want.shape, dtype=torch.int16, device="cuda:0")
+    a.score(out=outg); torch.cuda.synchronize()          # the workspace is allocated outside the capture
+    side = torch.cuda.Stream(); graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            a.score(out=outg)
+    for _ in range(2):
+        torch.cuda.synchronize(); outg.zero_(); graph.replay(); torch.cuda.synchronize()
+        assert np.array_equal(outg.cpu().numpy(), want), ("graph replay", algo)
 print("knobs ok")
 """
 
