@@ -1000,13 +1000,18 @@ static int seam_tiles()
     return n;
 }
 
-// Query rows align_hip scores per launch when the calls walk a query buffer (BGSA_HIP_ROW_AHEAD, 1..64; 1 = none).
+// Query rows align_hip scores per launch when the calls walk a query buffer (BGSA_HIP_ROW_AHEAD, 1..128; 1 = none).
 static int seam_row_ahead()
 {
     static const int n = [] {
         const char *e = getenv("BGSA_HIP_ROW_AHEAD");
-        const int v = e ? atoi(e) : 32;     // 10k x 1M through the reference's own pipeline: cal 1.93 / 1.66 / 1.47 s at 16 / 32 / 64
-        return (v >= 1 && v <= 64) ? v : 32;
+        // 10k x 1M x 150 bp through the reference's own pipeline (oracle/_ref/original_hip/aligner -N 16; scripts/r03_rowahead.sh,
+        // profiles/r03_rowahead.txt), its `cal GCUPS` at 32 / 50 / 64 / 100 / 128 rows: 121-140k / 133k / 150-158k / 230k / 94k.
+        // 100 is the reference's REF_BUCKET_COUNT (config.h): a launch is then exactly one of its query blocks, the
+        // speculative successor launch the next block, scored while the reference's writer thread still writes this one —
+        // its cal timer only sees the copy-out.  Rows that straddle blocks (64, 128) leave launches half used.
+        const int v = e ? atoi(e) : 100;
+        return (v >= 1 && v <= 128) ? v : 100;
     }();
     return n;
 }
