@@ -714,7 +714,9 @@ print("rows ok", m.value)
 @pytest.mark.parametrize("env", [{"BGSA_HIP_ROW_ARENA": "0"},                          # no page-locked arena: every row staged and copied
                                  {"BGSA_HIP_ROW_AHEAD": "1"},                          # one row per launch, nothing ahead of the calls
                                  {"BGSA_HIP_ROW_AHEAD": "7", "BGSA_HIP_ROW_ARENA": "0"},
-                                 {"BGSA_HIP_ROW_AHEAD": "64"}])
+                                 {"BGSA_HIP_ROW_AHEAD": "64"},
+                                 {"BGSA_HIP_ROW_AHEAD": "128"},                        # the most the knob takes
+                                 {}])                                                  # the default: 100 rows, the reference's query block
 def test_align_hip_row_cache_variants(env):
     """align_hip walking a query buffer with the row cache's fallbacks and knobs (read once per process: child processes)."""
     import os
