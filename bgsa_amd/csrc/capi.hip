@@ -1000,7 +1000,7 @@ static int seam_tiles()
     return n;
 }
 
-// Query rows align_hip scores per launch when the calls walk a query buffer (BGSA_HIP_ROW_AHEAD, 1..128; 1 = none).
+// Query rows align_hip scores per launch when the calls walk a query buffer (BGSA_HIP_ROW_AHEAD, 1..256; 1 = none).
 static int seam_row_ahead()
 {
     static const int n = [] {
@@ -1011,7 +1011,7 @@ static int seam_row_ahead()
         // speculative successor launch the next block, scored while the reference's writer thread still writes this one —
         // its cal timer only sees the copy-out.  Rows that straddle blocks (64, 128) leave launches half used.
         const int v = e ? atoi(e) : 100;
-        return (v >= 1 && v <= 128) ? v : 100;
+        return (v >= 1 && v <= 256) ? v : 100;
     }();
     return n;
 }
@@ -1398,9 +1398,15 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 g_host.calls++;
                 const size_t r_groups = r->bytes / host_group_bytes, first_group = (peq_host - r->host) / host_group_bytes;
                 const size_t n_sub = r_groups * HIP_V_NUM, row_size = n_sub * esz, stride = static_cast<size_t>(ref_len) + 1;
-                // rows per launch: two launches in flight must fit the row arena several times over (huge buckets: fewer rows)
-                const int ahead = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(seam_row_ahead()),
-                                                                                     kRowArenaBytes / std::max<size_t>(row_size, 1) / 4)));
+                // rows per launch: the launch the host threads read, the one being scored behind it and the rows of the launches
+                // before them that are still in some thread's hands must all have their slot in the row arena (512 slots of
+                // the bucket's row size, fewer for rows over 2 MB): with a quarter of the slots per launch the arena was exactly
+                // full, every new launch evicted rows that had not been read yet, and the reference's pipeline reported 94k GCUPS
+                // where 100 rows gave 230-290k (1M subjects, 128 rows: 821 launches on a miss instead of 5;
+                // profiles/r03_rowahead.txt).  A fifth of the slots at most.
+                const size_t slot_bytes = (row_size + 4095) & ~size_t(4095);
+                const size_t arena_slots = std::min(kRowArenaBytes, std::max(size_t(64) << 20, 512 * slot_bytes)) / std::max<size_t>(slot_bytes, 1);
+                const int ahead = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(seam_row_ahead()), arena_slots / 5)));
                 auto find_row = [&](const char *qrow_bytes) -> CachedRow * {
                     for (CachedRow &c : g_host.rows)
                         if (c.range_gen == r->gen && c.read_len == read_len && c.query.size() == static_cast<size_t>(ref_len) &&

@@ -20,7 +20,9 @@
 #include <stdint.h>
 
 #define READ_BUCKET_SIZE 114857600   /* original/BGSA_CPU/config.h:6 */
+#ifndef REF_BUCKET_COUNT             /* (-DREF_BUCKET_COUNT=<n>: the builds that check the seam with other query blocks) */
 #define REF_BUCKET_COUNT 100         /* :13 */
+#endif
 #define CHAR_NUM 5                   /* :18 */
 #define common_write_t int16_t       /* :20 */
 
