@@ -248,6 +248,24 @@ def test_reference_host_pipeline_on_the_gpu_library(tmp_path, name, binary):
     assert "GCUPS" in report
 
 
+@pytest.mark.parametrize("binary", ["aligner_block64", "aligner_block250"])
+@pytest.mark.parametrize("threads,ahead", [(8, None), (3, "7"), (16, "256")])
+def test_reference_host_pipeline_other_query_blocks(tmp_path, oracle, binary, threads, ahead):
+    """The reference's host files built with REF_BUCKET_COUNT = 64 and 250 instead of 100 (oracle/Makefile): the align_hip seam's
+    read-ahead (100 rows by default, the reference's own block) then no longer lines up with the caller's blocks, and with 250
+    the OpenMP threads start beyond the rows read ahead.  That may cost time, never results: 700 queries = several blocks of
+    either size with a ragged last one."""
+    if not (REF_HIP / binary).exists():
+        pytest.skip("oracle/_ref/original_hip not built (needs /root/reference at build time)")
+    q = oracle.gen_reads(171, 700, 150)
+    s = oracle.gen_reads(172, 64 * 9 + 5, 150)
+    s[:40] = oracle.mutate(q[np.arange(40) * 17 % 700], np.arange(40) % 11, 173)
+    g = {"queries": q, "subjects": s}
+    got, report = _run_reference_host(tmp_path, g, binary, threads=threads, env_extra={"BGSA_HIP_ROW_AHEAD": ahead} if ahead else None)
+    assert np.array_equal(got, oracle.myers64(q, s))
+    assert "GCUPS" in report
+
+
 def test_reference_host_pipeline_other_scores(tmp_path, oracle):
     sets = [x for x in B.score_sets() if x != (2, -3, -5)]
     if not (REF_HIP / "aligner_bitpal").exists() or not sets:
