@@ -357,9 +357,17 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    // a BitPAl row is 2-4x a Myers row.  Counter where the loop's registers cost no occupancy (plain kernels of up to 8 words
-    // hold <= 5 waves' worth)
-    const TaskPlan plan = plan_tasks(nq, n_groups, static_cast<long long>(ref_len) * NW * 2, 16, NW <= 8);
+    // a BitPAl row is 2-4x a Myers row.  Counter where the loop's registers cost no wave — asked of the runtime per score set,
+    // width and mode, once (2/-3/-5: 5 words 98 -> 108 VGPRs, four waves per SIMD either way; 8 words 155 -> 169 would be
+    // three -> two: 256 bp ran 10 % slower with it, profiles/r03_length_sweep.txt)
+    static const bool counter_costs_no_wave[2] = {
+        [] { int a = 0, b = 0;
+             return hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bitpal_asm_kernel<NW, false, false>, 256, 0) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bitpal_asm_kernel<NW, false, true>, 256, 0) == hipSuccess && b >= a && a > 0; }(),
+        [] { int a = 0, b = 0;
+             return hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bitpal_asm_kernel<NW, true, false>, 256, 0) == hipSuccess &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bitpal_asm_kernel<NW, true, true>, 256, 0) == hipSuccess && b >= a && a > 0; }()};
+    const TaskPlan plan = plan_tasks(nq, n_groups, static_cast<long long>(ref_len) * NW * 2, 16, NW <= 8 && counter_costs_no_wave[semi ? 1 : 0]);
     const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),
