@@ -192,6 +192,9 @@ REF_VARIANTS = {
     "original_sse": ("original_sse", np.int16),   # Myers SSE 4x32
     "original_avx2": ("original_avx2", np.int16),  # BitPAl (2,-3,-5) AVX2 8x32
     "banded_cpu": ("banded_cpu", np.int8),        # banded Myers scalar 64-bit
+    # Myers AVX2 8x32: the generator's AVX2 instance of original/BGSA_SSE/align_core.c (derive_avx2_myers.py) on
+    # original/BGSA_AVX2's host files — reference-derived, used as the Myers cpu_baseline
+    "original_avx2_myers": ("original_avx2_myers", np.int16),
 }
 
 

@@ -3,7 +3,7 @@
 # stats and PMC passes per config (separate --pmc runs, as MI355X_MICROARCH.md §HBM prescribes).
 # Run on the GPU box from the repo root:  bash scripts/gpu_round_report.sh <tag> [parts]
 #   parts: any of  tests bench prof pmc banded ubench  (default: all);  CONFIGS="4" limits bench/prof/pmc to config 4
-tag=${1:-r03}
+tag=${1:-r04}
 parts=${2:-"tests bench prof pmc banded"}
 CONFIGS=${CONFIGS:-"2 3 4 5"}      # restrict the bench / prof / pmc parts to some configs
 out=gpurun_out/$tag
@@ -30,7 +30,7 @@ if has bench; then
 fi
 if has prof; then
   for c in $CONFIGS; do
-    step "prof cfg$c" 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-total --no-clock-probe --banded-variants '' > $out/prof_cfg$c.log 2>&1
+    step "prof cfg$c" 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cfg$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-total --no-clock-probe --no-other-configs --banded-variants '' > $out/prof_cfg$c.log 2>&1
   done
 fi
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU"
@@ -39,7 +39,7 @@ if has pmc; then
     [ $c = 3 ] && continue    # config 3: the `banded` part, per subject mix
     for grp in FETCH_SIZE WRITE_SIZE SQ; do
       ctrs=$grp; [ $grp = SQ ] && ctrs=$SQ
-      step "pmc cfg$c $grp" 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc_cfg${c}_$grp -- python3 bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-total --no-clock-probe > $out/pmc_cfg${c}_$grp.log 2>&1
+      step "pmc cfg$c $grp" 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc_cfg${c}_$grp -- python3 bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-total --no-clock-probe --no-other-configs > $out/pmc_cfg${c}_$grp.log 2>&1
     done
   done
 fi

@@ -139,6 +139,11 @@ def main() -> int:
         if variant == "original_cpu" and s.shape[0] >= 8:
             sse, _ = O.run_reference("original_sse", q, s, threads=2)
             assert (sse == scores).all(), f"{name}: BGSA_SSE != BGSA_CPU"
+            # ... and so must the generator's AVX2 instance of the SSE kernel (oracle/derive_avx2_myers.py), the Myers
+            # cpu_baseline of bench.py
+            if O.have_reference("original_avx2_myers"):
+                avx, _ = O.run_reference("original_avx2_myers", q, s, threads=2)
+                assert (avx == scores).all(), f"{name}: the derived AVX2 Myers instance != BGSA_CPU"
         path = GOLDEN / f"{name}.npz"
         if args.check:
             old = np.load(path)

@@ -46,3 +46,69 @@ def test_pmc_pass_of_another_build_is_refused(tmp_path, monkeypatch):
     vals, src = bench.pmc_values(2, "", "bbbbbbbbbbbbbbbb")        # the same build: used, without the meta row
     assert src == "r03_cfg2_pmc.csv" and vals == {"SQ_INSTS_VALU": 1177813002817.0, "FETCH_SIZE": 15297673.0}
     assert bench.pmc_values(4, "", "bbbbbbbbbbbbbbbb") == (None, None)   # no pass at all
+
+
+def _run_watchdog_script(body: str, timeout=120):
+    """A child process that arms bench.py's RunWatchdog and then runs `body` (the watchdog ends it with os._exit)."""
+    import subprocess
+    import textwrap
+    script = textwrap.dedent("""
+        import argparse, importlib.util, sys, time
+        spec = importlib.util.spec_from_file_location("bench_under_test", r"{bench}")
+        bench = importlib.util.module_from_spec(spec); sys.modules["bench_under_test"] = bench; spec.loader.exec_module(bench)
+        args = argparse.Namespace(config=2, steps=3, warmup=1)
+    """).format(bench=ROOT / "bench.py") + textwrap.dedent(body)
+    return subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+
+
+def test_watchdog_prints_a_stub_line_and_exits_3_when_nothing_was_measured():
+    """A hang before the timed region (RCCL init, the first barrier, the query broadcast): rank 0's line is a stub that
+    names the stage, rccl_ok is false, exit status 3."""
+    import json
+    p = _run_watchdog_script("""
+        wd = bench.RunWatchdog(0, 8, args, limit=0.3)
+        wd.stage = "init_process_group(nccl)"
+        time.sleep(30)
+    """)
+    assert p.returncode == 3, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["value"] is None and r["n_gpus"] == 8 and r["rccl_ok"] is False and r["unit"] == "GCUPS"
+    assert r["watchdog"]["fired"] and r["watchdog"]["stage"] == "init_process_group(nccl)"
+
+
+def test_watchdog_keeps_the_measured_line_and_a_leg_limit_marks_its_leg():
+    import json
+    p = _run_watchdog_script("""
+        wd = bench.RunWatchdog(0, 2, args, limit=60)
+        wd.result = {"metric": "m", "value": 123.0, "gather_ok": None, "rccl_ok": None}
+        wd.stage = "gather leg"
+        wd.leg(0.3, "gather leg did not finish", lambda line: line.update(gather_ok=False))
+        time.sleep(30)
+    """)
+    assert p.returncode == 3, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["value"] == 123.0 and r["gather_ok"] is False and r["rccl_ok"] is False and r["watchdog"]["stage"] == "gather leg"
+
+
+def test_watchdog_of_a_peer_rank_prints_nothing_and_a_cancelled_one_does_not_fire():
+    p = _run_watchdog_script("""
+        wd = bench.RunWatchdog(1, 2, args, limit=0.3)
+        time.sleep(30)
+    """)
+    assert p.returncode == 3 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = _run_watchdog_script("""
+        wd = bench.RunWatchdog(0, 1, args, limit=0.5)
+        wd.cancel()
+        time.sleep(1.0)
+        print("clean")
+    """)
+    assert p.returncode == 0 and "clean" in p.stdout
+
+
+def test_checksum_needs_no_int64_copy_of_the_matrix():
+    import torch
+    bench = _bench()
+    out = torch.randint(-150, 1, (1000, 130), dtype=torch.int16)
+    assert bench.checksum_int64(out, 100, rows_per_block=64) == int(out[:, :100].to(torch.int64).sum())

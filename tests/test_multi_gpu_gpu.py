@@ -78,7 +78,7 @@ def _bench_two_ranks(extra_env, extra_args=(), want_rc=0):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert (p.returncode == 0) if want_rc == 0 else (p.returncode != 0), p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
     return json.loads(lines[0])
 
 
@@ -93,7 +93,19 @@ def test_bench_line_for_two_ranks(config):
     g = r["gather"]
     assert "error" not in g, g
     assert g["root_blocks_checked"] >= 3 and g["gcups_with_gather"] > 0
-    assert "cpu_baseline" not in r and "total_gcups" not in r       # rank 0 at N = 1 only
+    # rank 0 at N = 1 only — and the line says so instead of omitting the keys
+    assert "skipped" in r["cpu_baseline"] and "skipped" in r["total_gcups"] and "skipped" in r["other_configs"]
+    assert r["rccl_ok"] is None                    # gloo rehearsal: no RCCL byte moved, the line does not claim one did
+    assert r["preflight"]["all_gather"]["content_ok"] is True and len(r["ranks"][1]["peer_access"]) >= 1
+    if config == 2:
+        # the default invocation at N > 1 also times BASELINE configs[4]: ONE bucket of 1000 bp reads cut by plan_shards
+        st = r["strong"]
+        assert "error" not in st, st
+        assert st["scaling"] == "strong" and st["length_bp"] == 1000 and st["subjects_total"] == 64000
+        assert [x["subjects"] for x in st["ranks"]] == [32000, 32000] and all(x["kernel_ms"] > 0 for x in st["ranks"])
+        assert st["gcups"] > 0 and st["gather"]["gcups_with_gather"] > 0 and st["gather"]["root_blocks_checked"] >= 3
+    else:
+        assert "strong" not in r
     # the line proves that two ranks ran: gathered through the process group, one entry per rank with its own kernel time
     assert r["gather_ok"] is True
     assert [x["rank"] for x in r["ranks"]] == [0, 1] and r["ranks_seen"] == 2
@@ -109,6 +121,40 @@ def test_bench_line_survives_a_gather_that_never_finishes():
     assert "did not finish" in r["gather"]["error"] and r["gather_ok"] is False
 
 
+def test_bench_line_when_a_rank_never_joins():
+    """The likeliest first failure on a real node is a hang in RCCL's init.  One rank never reaches init_process_group:
+    the whole-run watchdog (armed before the group exists) ends the run within its limit, rank 0 prints a parseable stub
+    that names the stage, rccl_ok = false, exit status non-zero."""
+    import time
+    t0 = time.time()
+    r = _bench_two_ranks({"BGSA_BENCH_TEST_HANG_RANK": "1", "BGSA_BENCH_TIMEOUT": "25"}, ("--config", "2"), want_rc=3)
+    assert time.time() - t0 < 240
+    assert r["value"] is None and r["rccl_ok"] is False and r["n_gpus"] == 2
+    assert r["watchdog"]["fired"] and "init_process_group" in r["watchdog"]["stage"]
+
+
+def test_bench_line_carries_the_other_baseline_configs():
+    """N = 1, the default invocation: configs 3, 4 and 5 are timed after the timed region and land in the same line
+    (here at reduced sizes), each with its kernel, time, rate and checksum; the whole run stays under its watchdog."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--nq", "300", "--ns", "64000",
+           "--no-cpu-baseline", "--no-total"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    oc = r["other_configs"]
+    assert set(oc) >= {"3", "4", "5"} and "watchdog" not in r and r["rccl_ok"] is None
+    for cid, length, kern in (("3", 150, "banded"), ("4", 150, "bitpal"), ("5", 1000, "myers")):
+        e = oc[cid]
+        assert "error" not in e, e
+        assert e["length_bp"] == length and kern in e["kernel"] and e["kernel_ms"] > 0 and e["gcups"] > 0
+        assert "SIZE OVERRIDDEN" in e["workload"] and isinstance(e["checksum"], int)
+    assert oc["3"]["banded_mix"]["name"] == "planted" and 0 < oc["3"]["banded_mix"]["fraction"] < 0.01
+    assert oc["4"]["issued"]["frac"] and oc["5"]["issued"]["frac"]          # exact generator counts at any size
+
+
 def test_bench_line_carries_the_sustained_clock_without_paying_for_it():
     """N = 1: the clock probes (eight sleeping one-wave workgroups on a stream of the library's own) run beside the timed
     kernels and are released BEFORE the closing device-wide synchronize — a first version left them to their time bound
@@ -118,7 +164,7 @@ def test_bench_line_carries_the_sustained_clock_without_paying_for_it():
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--nq", "2000", "--ns", "256000",
-           "--no-cpu-baseline", "--no-total"]
+           "--no-cpu-baseline", "--no-total", "--no-other-configs"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
