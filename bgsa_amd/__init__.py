@@ -89,6 +89,8 @@ def lib() -> ctypes.CDLL:
     L.bgsa_hip_stream_faults.argtypes = [i32]
     L.bgsa_hip_debug_inject_stream_fault.argtypes = [i32]
     L.bgsa_hip_set_auto_resident.argtypes = [i32]
+    L.bgsa_hip_set_strict_resident.argtypes = [i32]
+    L.bgsa_hip_stale_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.bgsa_hip_bucket_resident.argtypes = [vp, sz, i32]
     L.bgsa_hip_bucket_release.argtypes = [vp]
     u64p = ctypes.POINTER(ctypes.c_uint64)

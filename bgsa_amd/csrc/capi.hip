@@ -430,6 +430,15 @@ int bgsa_hip_set_device(int device)
     BGSA_HIP_TRY(hipSetDevice(device));
     return BGSA_HIP_OK;
 }
+int bgsa_hip_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    BGSA_HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return BGSA_HIP_OK;
+}
+
 int bgsa_hip_malloc(void **dptr, size_t bytes)
 {
     if (!dptr) return BGSA_HIP_EINVAL;
@@ -749,7 +758,50 @@ struct ResidentRange {
     int device = -1;
     bool uploaded = false;
     uint64_t gen = 0;                      // identity of this content: a rewritten range gets a new one
+    uint64_t fp = 0;                       // range_fingerprint() of the host bytes the device copy was made from
+    std::vector<unsigned char> shadow;     // strict mode only: those host bytes themselves
 };
+
+// A registered range that the caller rewrites by other means than hip_handle_reads (a memcpy of a saved bucket, a host
+// that builds Peq itself and forgets bgsa_hip_bucket_resident) must not be scored from the stale device copy in silence
+// (SURVEY 8(b) "Ownership": the callee keeps no state between calls; the KNC precedent, BGSA_KNC/cal_mic.c:348-356,
+// justifies residency, not silence).  Every scoring call therefore fingerprints the host range it is about to use —
+// kFingerprintLines cache lines at fixed positions, first and last among them: a few hundred nanoseconds once the lines
+// are in the calling core's cache — and a range whose fingerprint changed is uploaded again (its cached rows dropped).
+// A rewrite that changes none of the sampled lines is only caught by the full comparison of
+// BGSA_HIP_STRICT_RESIDENT=1 / bgsa_hip_set_strict_resident(1), which keeps a host copy of what was uploaded.
+static constexpr size_t kFingerprintLines = 34;
+static uint64_t range_fingerprint(const unsigned char *p, size_t bytes)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+    const size_t lines = bytes / 64;
+    auto mix = [&](uint64_t w) { h = (h ^ w) * 0x100000001B3ull; h ^= h >> 29; };
+    if (lines < 2) {
+        for (size_t i = 0; i < bytes; i++) mix(p[i]);
+        return h;
+    }
+    const size_t n = std::min(lines, kFingerprintLines);
+    for (size_t j = 0; j < n; j++) {
+        // evenly spread over the range; with a group's five class planes 4 x word_num lines each, about a fifth of the
+        // samples fall into the plane of a class no read contains (all zeros in every bucket) — the others tell buckets apart
+        const size_t line = (j * (lines - 1)) / (n - 1);
+        uint64_t w[8];
+        memcpy(w, p + line * 64, 64);
+        for (uint64_t x : w) mix(x);
+    }
+    return h;
+}
+static std::atomic<int> g_strict_resident{-1};   // -1: not decided yet (BGSA_HIP_STRICT_RESIDENT)
+static bool strict_resident()
+{
+    int v = g_strict_resident.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("BGSA_HIP_STRICT_RESIDENT");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_strict_resident.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
 
 // 32-bit words per (class, lane) of a HOST Peq buffer whose caller passed `word_num`, or -1.  Myers and
 // BitPAl: the library's own layout only.  Banded: the library's Mext layout (ceil(len/32)+3 words of
@@ -903,6 +955,16 @@ static size_t row_arena_slots_out()
     std::lock_guard<std::mutex> lock(g_arena.mu);
     return g_arena.n_slots - g_arena.free_slots.size();
 }
+// Slots the arena has for rows of `size` bytes: the arena that EXISTS once it is carved (it may have been halved when
+// hipHostMalloc refused, or carved for another bucket's rows), the carving rule before that.
+static size_t row_arena_slots_for(size_t size)
+{
+    const size_t slot = (size + 4095) & ~size_t(4095);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    if (g_arena.base && g_arena.slot_bytes) return size <= g_arena.slot_bytes ? g_arena.n_slots : 0;
+    if (g_arena.tried) return 0;      // no arena could be had: rows take the heap / staged path
+    return std::min(kRowArenaBytes, std::max(size_t(64) << 20, 512 * slot)) / std::max<size_t>(slot, 1);
+}
 static bool row_arena_too_small(size_t size)
 {
     std::lock_guard<std::mutex> lock(g_arena.mu);
@@ -943,7 +1005,7 @@ struct HostSeam {
     std::vector<unsigned char> content_copy;   // what d_content holds
     std::vector<ResidentRange> ranges;
     bool auto_resident = true;
-    uint64_t peq_uploads = 0, peq_upload_bytes = 0, calls = 0;
+    uint64_t peq_uploads = 0, peq_upload_bytes = 0, calls = 0, stale_ranges = 0;
     int reserve(void **p, size_t *cap, size_t need)
     {
         if (need <= *cap) return BGSA_HIP_OK;
@@ -1077,6 +1139,27 @@ static ResidentRange *resident_range(const unsigned char *peq_host, size_t bytes
         if (peq_host < r.host || peq_host + bytes > r.host + r.bytes || r.w_host != w_host || r.w_dev != w_dev ||
             (peq_host - r.host) % host_group_bytes != 0)
             continue;
+        if (r.uploaded && r.device == g_host.device) {
+            // the bytes the device copy was made from must still be there (see range_fingerprint above); strict mode
+            // compares every byte of the part this call is about to use
+            bool stale = range_fingerprint(r.host, r.bytes) != r.fp;
+            if (!stale && !r.shadow.empty())
+                stale = memcmp(r.shadow.data() + (peq_host - r.host), peq_host, bytes) != 0;
+            if (stale) {
+                g_host.stale_ranges++;
+                g_range_epoch.fetch_add(1, std::memory_order_release);
+                for (size_t j = 0; j < g_host.rows.size();) {      // rows scored from the old content go with it
+                    if (g_host.rows[j].range_gen == r.gen) {
+                        g_host.row_bytes -= g_host.rows[j].scores->size;
+                        g_host.rows.erase(g_host.rows.begin() + j);
+                    } else {
+                        j++;
+                    }
+                }
+                r.gen = g_host.next_gen++;
+                r.uploaded = false;
+            }
+        }
         if (!r.uploaded || r.device != g_host.device) {
             const size_t r_groups = r.bytes / host_group_bytes;
             if (r.dev && r.device != g_host.device) { (void)hipFree(r.dev); r.dev = nullptr; }
@@ -1085,6 +1168,17 @@ static ResidentRange *resident_range(const unsigned char *peq_host, size_t bytes
                 die("resident bucket");
             }
             if (upload_peq(r.dev, r.host, r_groups, w_host, w_dev, s)) die("resident bucket");
+            r.fp = range_fingerprint(r.host, r.bytes);
+            if (strict_resident()) {
+                // the copy above may still be reading a pageable source through the runtime's staging: the shadow must hold
+                // exactly what travels, so let it finish first (strict mode is a debugging aid, not a fast path)
+                if (hipStreamSynchronize(s) != hipSuccess) die("resident bucket");
+                r.shadow.assign(r.host, r.host + r.bytes);
+                r.fp = range_fingerprint(r.host, r.bytes);
+            } else {
+                r.shadow.clear();
+                r.shadow.shrink_to_fit();
+            }
             r.device = g_host.device;
             r.uploaded = true;
             g_host.peq_uploads++;
@@ -1099,6 +1193,25 @@ int bgsa_hip_set_auto_resident(int on)
 {
     std::lock_guard<std::mutex> turn(g_seam);
     g_host.auto_resident = on != 0;
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_set_strict_resident(int on)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    g_strict_resident.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_range_epoch.fetch_add(1, std::memory_order_release);   // no thread keeps serving from a row checked the other way
+    for (ResidentRange &r : g_host.ranges) {                 // ranges uploaded before the switch get their shadow on the next call
+        if (on && r.uploaded && r.shadow.empty()) r.uploaded = false;
+        if (!on) { r.shadow.clear(); r.shadow.shrink_to_fit(); }
+    }
+    return BGSA_HIP_OK;
+}
+
+int bgsa_hip_stale_ranges(uint64_t *count)
+{
+    std::lock_guard<std::mutex> turn(g_seam);
+    if (count) *count = g_host.stale_ranges;
     return BGSA_HIP_OK;
 }
 
@@ -1363,6 +1476,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
         int read_len = 0, word_num = 0;
         std::string query;
         std::shared_ptr<RowBuf> scores;
+        uint64_t range_fp = 0;     // fingerprint of the bucket's host bytes the row was scored from
     };
     static thread_local LastRow last;
     if (chunk_read_num > 0 && ref && read && results && ref_len > 0) {
@@ -1374,7 +1488,10 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 last.word_num == word_num && last.query.size() == static_cast<size_t>(ref_len) &&
                 peq_host >= last.range_host && peq_host + last.group_bytes * chunk_read_num <= last.range_host + last.range_bytes &&
                 (peq_host - last.range_host) % last.group_bytes == 0 && memcmp(&last.params, &params, sizeof params) == 0 &&
-                memcmp(last.query.data(), ref, ref_len) == 0) {
+                memcmp(last.query.data(), ref, ref_len) == 0 &&
+                // the bucket's bytes are still the ones this row was scored from (a rewrite the library was not told about
+                // sends the call down the locked path, which uploads the range again); strict mode always takes that path
+                !strict_resident() && range_fingerprint(last.range_host, last.range_bytes) == last.range_fp) {
                 const size_t esz = result_elem_size(params.algo);
                 memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
                        last.scores->p + (peq_host - last.range_host) / last.group_bytes * HIP_V_NUM * esz,
@@ -1404,8 +1521,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 // full, every new launch evicted rows that had not been read yet, and the reference's pipeline reported 94k GCUPS
                 // where 100 rows gave 230-290k (1M subjects, 128 rows: 821 launches on a miss instead of 5;
                 // profiles/r03_rowahead.txt).  A fifth of the slots at most.
-                const size_t slot_bytes = (row_size + 4095) & ~size_t(4095);
-                const size_t arena_slots = std::min(kRowArenaBytes, std::max(size_t(64) << 20, 512 * slot_bytes)) / std::max<size_t>(slot_bytes, 1);
+                const size_t arena_slots = row_arena_slots_for(row_size);
                 const int ahead = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(seam_row_ahead()), arena_slots / 5)));
                 auto find_row = [&](const char *qrow_bytes) -> CachedRow * {
                     for (CachedRow &c : g_host.rows)
@@ -1601,14 +1717,17 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                     g_host.last_miss_stride = stride;
                     std::shared_ptr<RowBatch> bt = issue(ref, n_rows, in_block);
                     g_host.rows_ahead += static_cast<uint64_t>(n_rows - 1);
-                    chain(bt);
-                    wait_batch(bt);
+                    // hold the served row's buffer BEFORE the launch behind this one is issued: that issue may evict cache
+                    // entries — with an arena smaller than assumed, or many threads holding slots, even unread rows of the
+                    // batch just issued — and the buffer (and the copy landing in it) lives as long as this reference
                     CachedRow *c = find_row(ref);
                     if (!c) {
-                        set_error_text("align_hip: the row just scored is not in the cache");
+                        set_error_text("align_hip: the row just issued is not in the cache");
                         die("align_hip");
                     }
                     row = c->scores;
+                    chain(bt);
+                    wait_batch(bt);
                     g_row_ns.fetch_add(now_ns() - t_row, std::memory_order_relaxed);
                 }
                 row->pending.reset();   // served: nothing in flight behind this buffer any more
@@ -1621,6 +1740,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 last.word_num = word_num;
                 last.query.assign(ref, ref + ref_len);
                 last.scores = row;
+                last.range_fp = r->fp;
                 turn.unlock();   // the copy needs no lock: the row is shared, immutable
                 memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
                        row->p + first_group * HIP_V_NUM * esz, static_cast<size_t>(chunk_read_num) * HIP_V_NUM * esz);

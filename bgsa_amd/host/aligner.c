@@ -526,14 +526,43 @@ int main(int argc, char **argv)
     if (getenv("BGSA_RESULT_RESIDENT_GB")) resident_gb = atof(getenv("BGSA_RESULT_RESIDENT_GB"));
     int resident = !(getenv("BGSA_RESULT_RESIDENT") && getenv("BGSA_RESULT_RESIDENT")[0] == '0') &&
                    (double)ref_count * (double)max_reads * (double)esz <= resident_gb * 1e9 && n_launch <= 65536;
+    /* the widest slice any device can be handed: sizes every per-device allocation once */
+    plan_slices(dev, n_dev, max_reads / HIP_V_NUM);
+    /* ... and only when they fit the memory each device really has free: the limit above is a constant, the card may be
+     * smaller, shared, or already hold another job's buffers.  Everything this pipeline allocates per device — rows, Peq,
+     * queries, two launch tiles, two workspaces — plus the bucket's scores plus BGSA_RESULT_RESIDENT_HEADROOM_GB (2) must
+     * fit into what hipMemGetInfo reports; otherwise the ring pipeline of round 2 runs the same job.
+     * (BGSA_DEVICE_FREE_GB overrides the reported figure: tests.) */
+    if (resident) {
+        double headroom_gb = 2.0;
+        if (getenv("BGSA_RESULT_RESIDENT_HEADROOM_GB")) headroom_gb = atof(getenv("BGSA_RESULT_RESIDENT_HEADROOM_GB"));
+        for (int d = 0; d < n_dev && resident; d++) {
+            size_t free_b = 0, total_b = 0;
+            CK(bgsa_hip_set_device(dev[d].gpu));
+            CK(bgsa_hip_mem_info(&free_b, &total_b));
+            double free_bytes = (double)free_b;
+            if (getenv("BGSA_DEVICE_FREE_GB")) free_bytes = atof(getenv("BGSA_DEVICE_FREE_GB")) * 1e9;
+            const double cap = (double)(dynamic ? max_reads : dev[d].count + 2 * HIP_V_NUM);
+            /* several entries of -g may name the same card (tests, -g 0,0,0): they share its memory */
+            int sharers = 0;
+            for (int o = 0; o < n_dev; o++) sharers += dev[o].gpu == dev[d].gpu;
+            const double base = cap * (double)row + (double)bgsa_hip_group_words(algo, word_num, threshold) * sizeof(hip_read_t) * (cap / HIP_V_NUM) +
+                                (double)qsize + 2.0 * ((double)launch_queries * cap * (double)esz + (double)work_bytes);
+            const double need = (base + (double)ref_count * cap * (double)esz) * sharers + headroom_gb * 1e9;
+            if (need > free_bytes) {
+                fprintf(stderr, "[aligner] the bucket's scores (%.2f GB per device) do not fit device %d's free memory (%.2f GB free, "
+                                "%.2f GB needed with %.1f GB headroom): ring pipeline instead of resident results\n",
+                        (double)ref_count * cap * (double)esz / 1e9, dev[d].gpu, free_bytes / 1e9, need / 1e9, headroom_gb);
+                resident = 0;
+            }
+        }
+    }
 
     /* what goes through a ring slot: a whole launch in the ring pipeline; one block of REF_BUCKET_COUNT queries in resident mode,
      * where the copy-out is independent of the launches (less page-locked memory to set up: 4 x 152 MB instead of 3 x 609 MB) */
     const int64_t slot_queries = resident ? REF_BUCKET_COUNT : launch_queries;
     const size_t block_bytes = (size_t)slot_queries * (size_t)max_reads * esz;
 
-    /* the widest slice any device can be handed: sizes every per-device allocation once */
-    plan_slices(dev, n_dev, max_reads / HIP_V_NUM);
     void *h_rows;
     CK(bgsa_hip_malloc_host(&h_rows, rows_bytes));
     for (int d = 0; d < n_dev; d++) {
@@ -869,6 +898,8 @@ int main(int argc, char **argv)
      * in the KNC backend, cal_mic.c:150-152): here the GPU time of the scoring launches of every block (HIP events on the
      * block's stream; with several GPUs the slowest device's), copies and file I/O outside, as they are outside there. */
     printf("pipeline_busy_time  is %.2fs\n", pipeline_time);
+    printf("result_pipeline     is %s\n", resident ? "resident (the bucket's scores stay in HBM, copy-out behind the kernels)"
+                                                   : "ring (two launches in flight)");
     printf("cal_total_times     is %.2fs\n", cal_time);
     printf("total time          is %.2fs\n", total);
     const double cells = 1.0 * ref_len * ref_count * read_len * subjects_done;

@@ -158,6 +158,18 @@ size_t bgsa_hip_group_words(int algo, int word_num, int k);
  * malloc_mem() hands out page-locked memory for large blocks, so every buffer of the reference's
  * pipeline (cal_cpu.c:206-267) moves at full PCIe rate. */
 int bgsa_hip_set_auto_resident(int on);
+/* A resident range rewritten behind the library's back.  The contract above asks the caller to say so; when it does
+ * not (a memcpy of a saved bucket over the registered buffer, a host that fills Peq itself), the library still does
+ * not score from the stale device copy in silence: every scoring call — hip_cal_align_score, and align_hip on its
+ * locked and its lock-free path — fingerprints the host range (34 cache lines at fixed positions, first and last
+ * among them) and uploads the range again when the fingerprint differs from the one taken at upload; cached rows of
+ * the old content are dropped.  A rewrite that happens to leave all sampled lines unchanged (a few groups patched
+ * in place) is only caught in strict mode — BGSA_HIP_STRICT_RESIDENT=1 in the environment or
+ * bgsa_hip_set_strict_resident(1) — which keeps a host copy of what was uploaded and compares every byte of the
+ * part a call uses (a debugging aid: align_hip then always takes its locked path).  bgsa_hip_stale_ranges() counts
+ * the re-uploads either check caused.  (SURVEY 8(b) "Ownership"; BGSA_KNC/cal_mic.c:348-356.) */
+int bgsa_hip_set_strict_resident(int on);
+int bgsa_hip_stale_ranges(uint64_t *count);
 /* host_peq[0 .. bytes) holds whole groups in the library's own layout with word_num words. */
 int bgsa_hip_bucket_resident(const hip_read_t *host_peq, size_t bytes, int word_num);
 int bgsa_hip_bucket_release(const hip_read_t *host_peq);   /* NULL: all of them */
@@ -216,6 +228,8 @@ int bgsa_hip_set_device(int device);
 
 /* Plain device memory helpers so C hosts need no HIP headers. */
 int bgsa_hip_malloc(void **dptr, size_t bytes);
+/* free and total memory of the current device (hipMemGetInfo); either pointer may be NULL */
+int bgsa_hip_mem_info(size_t *free_bytes, size_t *total_bytes);
 int bgsa_hip_free(void *dptr);
 /* Page-locked host memory (full-rate asynchronous copies for the pipeline driver). */
 int bgsa_hip_malloc_host(void **hptr, size_t bytes);

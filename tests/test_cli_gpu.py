@@ -78,6 +78,24 @@ def test_cli_launch_blocks_and_writer_modes_give_the_same_file(tmp_path, oracle,
     assert "pipeline_busy_time" in report and "cal_total_times" in report
 
 
+@pytest.mark.parametrize("env,want", [({"BGSA_RESULT_RESIDENT_GB": "0.000001"}, "ring"),
+                                      ({"BGSA_RESULT_RESIDENT_GB": "100000", "BGSA_DEVICE_FREE_GB": "0.5"}, "ring"),
+                                      ({"BGSA_RESULT_RESIDENT_GB": "100000"}, "resident"),
+                                      ({"BGSA_RESULT_RESIDENT_GB": "100000", "BGSA_DEVICE_FREE_GB": "0.5", "GPUS": "0,0"}, "ring")])
+def test_cli_resident_results_only_when_they_fit_the_device(tmp_path, oracle, env, want):
+    """Resident results are the default — when the bucket's scores fit BGSA_RESULT_RESIDENT_GB AND the memory the device
+    really has free (hipMemGetInfo, with headroom): a limit set too high for the card must end in the ring pipeline with the
+    same file, not in a failed allocation.  BGSA_DEVICE_FREE_GB stands in for a small or busy card."""
+    q = oracle.gen_reads(195, 230, 150)
+    s = oracle.gen_reads(196, 700, 150)
+    g = {"queries": q, "subjects": s, "variant": "original_cpu", "k": -1}
+    env = dict(env)
+    gpus = env.pop("GPUS", "0")
+    got, report = _run_cli(tmp_path, g, bucket_bytes=448 * 151 + 10, extra_args=["-g", gpus], env_extra=env)
+    assert np.array_equal(got, oracle.myers64(q, s))
+    assert f"result_pipeline     is {want}" in report
+
+
 def test_reference_convert_reads_our_result_files(tmp_path):
     # the result / .info pair is the reference's format: its own `convert -r` must decode it
     ref_convert = ROOT / "oracle" / "_ref" / "original_cpu" / "convert"

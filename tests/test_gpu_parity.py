@@ -588,6 +588,87 @@ def test_host_seam_keeps_the_bucket_resident(oracle):
         L.bgsa_hip_bucket_release(None)
 
 
+def test_resident_bucket_rewritten_behind_the_librarys_back_is_not_scored_stale(oracle):
+    """A registered Peq range that the caller overwrites by other means than hip_handle_reads — a memmove of another
+    preprocessed bucket, here — must give the NEW bucket's scores through hip_cal_align_score and through align_hip (its
+    locked path and the lock-free path that serves a thread's last row): every scoring call fingerprints the host range
+    and uploads it again when the bytes changed (SURVEY 8(b) "Ownership"; BGSA_KNC/cal_mic.c:348-356).  A rewrite that
+    leaves every sampled cache line alone — one group patched in place — is the case the documented strict mode is for."""
+    L = B.lib()
+    nq, length, wn = 6, 150, 5
+    n = 64 * 40
+    q = oracle.gen_reads(91, nq, length)
+    s_a, _ = B.pad_rows(oracle.gen_reads(92, n, length))
+    s_b, _ = B.pad_rows(oracle.gen_reads(93, n, length))
+    s_a[:nq] = oracle.mutate(q, np.arange(nq), 94)
+    s_b[:nq] = oracle.mutate(q, np.arange(nq) + 3, 95)
+    want_a, want_b = oracle.myers64(q, s_a), oracle.myers64(q, s_b)
+    assert not np.array_equal(want_a, want_b)
+    L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
+    L.init_mapping_table()
+    _sa, seq_a, qmapped = _host_seam_inputs(L, q, s_a)
+    _sb, seq_b, _ = _host_seam_inputs(L, q, s_b)
+    gw = B.group_words(B.ALGO_MYERS, wn)
+    x = np.zeros(gw * (n // 64), dtype=np.uint32)       # the registered bucket
+    y = np.zeros_like(x)                                 # another bucket, preprocessed elsewhere ("saved")
+
+    def stale():
+        c = ctypes.c_uint64()
+        L.bgsa_hip_stale_ranges(ctypes.byref(c))
+        return c.value
+
+    def coarse():
+        out = np.zeros((nq, n), dtype=np.int16)
+        L.hip_cal_align_score(qmapped.ctypes.data, x.ctypes.data, out.ctypes.data, length, nq, length, n, 0, nq, wn, 27, None)
+        return out
+
+    def fine(chunk=7):
+        out = np.zeros((nq, n), dtype=np.int16)
+        groups = n // 64
+        for i in range(nq):
+            row = np.ascontiguousarray(qmapped[i * (length + 1):(i + 1) * (length + 1)])
+            for j in range(0, groups, chunk):
+                c = min(chunk, groups - j)
+                L.align_hip(row.ctypes.data, x[gw * j:].ctypes.data, length, length, wn, c, i * groups + j, out.ctypes.data, None)
+        return out
+
+    try:
+        L.hip_handle_reads(ctypes.byref(seq_a), x.ctypes.data, wn, 0, n)
+        L.hip_handle_reads(ctypes.byref(seq_b), y.ctypes.data, wn, 0, n)
+        s0 = stale()
+        assert np.array_equal(coarse(), want_a) and np.array_equal(fine(), want_a) and stale() == s0
+        # --- the whole bucket replaced by a memmove: no call told the library
+        ctypes.memmove(x.ctypes.data, y.ctypes.data, x.nbytes)
+        assert np.array_equal(coarse(), want_b)
+        assert stale() == s0 + 1
+        assert np.array_equal(fine(), want_b) and stale() == s0 + 1          # uploaded once, rows scored from the new copy
+        # --- and back, this time the fine seam sees it first: every thread's last row (the lock-free path) and the
+        # cached rows belong to the old content and must not be served
+        L.hip_handle_reads(ctypes.byref(seq_a), y.ctypes.data, wn, 0, n)     # y := bucket A (y itself is registered too)
+        ctypes.memmove(x.ctypes.data, y.ctypes.data, x.nbytes)
+        assert np.array_equal(fine(), want_a) and stale() == s0 + 2
+        assert np.array_equal(coarse(), want_a) and stale() == s0 + 2
+        # --- one group patched in place, away from every sampled line: the fingerprint cannot see it (documented), the
+        # strict mode does — through both seams
+        lines = x.nbytes // 64
+        sampled = {(j * (lines - 1)) // 33 for j in range(34)}
+        g_lines = gw * 4 // 64
+        victim = next(g for g in range(1, n // 64) if not any(g * g_lines <= ln < (g + 1) * g_lines for ln in sampled))
+        L.hip_handle_reads(ctypes.byref(seq_b), y.ctypes.data, wn, 0, n)     # y := bucket B
+        assert L.bgsa_hip_set_strict_resident(1) == 0
+        assert np.array_equal(coarse(), want_a)                              # strict mode takes its host copy of the range here
+        x[gw * victim: gw * (victim + 1)] = y[gw * victim: gw * (victim + 1)]
+        mixed = want_a.copy()
+        mixed[:, 64 * victim: 64 * (victim + 1)] = want_b[:, 64 * victim: 64 * (victim + 1)]
+        before = stale()
+        assert np.array_equal(fine(), mixed) and stale() == before + 1
+        assert np.array_equal(coarse(), mixed) and stale() == before + 1
+        assert L.bgsa_hip_stream_faults(1) == 0
+    finally:
+        L.bgsa_hip_set_strict_resident(0)
+        L.bgsa_hip_bucket_release(None)
+
+
 def test_align_hip_grid_uses_the_row_cache(oracle):
     """The reference's grid (cal_cpu.c:63-84) through align_hip: every (query, chunk) pair is a call; with the
     bucket resident each query is scored once against the whole bucket and the other calls copy their chunk."""
