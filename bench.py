@@ -122,9 +122,9 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
 
 
 KERNEL_SOURCES = {   # what defines the scoring kernel of an algorithm: its id stamps PMC passes and the bench line
-    B.ALGO_MYERS: ("myers_global.hip", "myers_rows_gen.inc", "long_kernels.hip", "bgsa_common.h"),
+    B.ALGO_MYERS: ("myers_global.hip", "myers_rows_gen.inc", "bgsa_common.h"),
     B.ALGO_BANDED: ("banded.hip", "banded_rows_gen.inc", "bgsa_common.h"),
-    B.ALGO_BITPAL: ("bitpal.hip", "bitpal_kernels.inl", "bitpal_rows_gen.inc", "long_kernels.hip", "bgsa_common.h"),
+    B.ALGO_BITPAL: ("bitpal.hip", "bitpal_kernels.inl", "bitpal_rows_gen.inc", "bgsa_common.h"),
 }
 
 

@@ -17,6 +17,9 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 # BGSA_HIP_LIB: another build of the same library (A/B measurements of generator variants)
 LIB_PATH = Path(os.environ["BGSA_HIP_LIB"]) if os.environ.get("BGSA_HIP_LIB") else HERE / "libbgsa_hip.so"
+# the A/B flavour of the same library (`make -C bgsa_amd/csrc ab`): additionally every measured-and-not-adopted kernel a
+# measurement knob can select and three more BitPAl score sets; the knob tests and A/B scripts load it through BGSA_HIP_LIB
+LIB_AB_PATH = HERE / "libbgsa_hip_ab.so"
 INCLUDE = HERE.parent / "include" / "bgsa_hip.h"
 
 ALGO_MYERS, ALGO_BANDED, ALGO_BITPAL = 0, 1, 2
@@ -38,7 +41,7 @@ class BgsaHipError(RuntimeError):
 def build_library(verbose: bool = False) -> Path:
     """Compile libbgsa_hip.so in-tree (hipcc --offload-arch=gfx950).  Works without a GPU."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.run(["make", "-C", str(HERE / "csrc"), "-j8"], check=True, stdout=out)
+    subprocess.run(["make", "-C", str(HERE / "csrc"), "-j8", "all", "ab"], check=True, stdout=out)
     subprocess.run(["make", "-C", str(HERE / "host")], check=True, stdout=out)  # aligner, convert (C)
     return LIB_PATH
 

@@ -66,6 +66,7 @@ __device__ __forceinline__ void band_row(T win, T &vp, T &vn, uint32_t &acc)
     acc += 1u - static_cast<uint32_t>(d0 & 1);
 }
 
+#if BGSA_AB_KERNELS
 // Compiler-scheduled kernel of the same algorithm (A/B reference for the asm kernels, selected by
 // BGSA_BANDED_IMPL=c).  T = band word: uint32_t for k <= 15, uint64_t for k <= 31.  The first four
 // 32-bit Mext words per class are register-resident (rows 0..31 need words 0..2); beyond that the
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void banded_kernel(
         dst[static_cast<size_t>(q - ref_start) * ld] = result;
     }
 }
+#endif  // BGSA_AB_KERNELS
 
 namespace { int banded_impl(); }
 
@@ -666,6 +668,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
 // on a list (LDS, per wave); when the list is nearly full or the wave's query tile is done, the listed pairs
 // are scored one per lane, densely, from row 0 (banded_asm_kernel, top of the query loop).  Whatever gets
 // onto the list is scored exactly, so where the first pass stops is a pure performance choice.
+#if BGSA_AB_KERNELS
 // ---- straight-line rows (k <= 15): banded_chunk_rows_asm32 ---------------------------------------------
 // Same task decomposition, tests, regrouping and final walk as banded_asm_kernel; what differs is how a row gets
 // its match words: the wave keeps them in LDS ([class][slot][lane] dwords, 3840 B per wave) and a row's token is the
@@ -771,6 +774,7 @@ __global__ __launch_bounds__(256) void pack_banded_tokens_kernel(const char *__r
     }
     tokens[tid] = c * 768u;
 }
+#endif  // BGSA_AB_KERNELS
 
 namespace {
 
@@ -851,6 +855,7 @@ int banded_groups()
     return v;
 }
 
+#if BGSA_AB_KERNELS
 int launch_chunk(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len, int64_t read_count,
                  int ref_start, int ref_end, int word_num, int k, void *d_workspace, hipStream_t stream)
 {
@@ -876,6 +881,7 @@ int launch_chunk(const char *d_content, const uint32_t *d_peq, int8_t *d_results
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
+#endif  // BGSA_AB_KERNELS
 
 int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len, int64_t read_count,
                int ref_start, int ref_end, int word_num, int k, void *d_workspace, hipStream_t stream)
@@ -924,11 +930,13 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
                            fault, d_content, ref_start, len, push_row, push_row_solid, solid_limit, push_max, static_cast<uint32_t>(cut),
                            counter);
     }
+#if BGSA_AB_KERNELS
     else if (phase > 0)
         hipLaunchKernelGGL((banded_asm_kernel<false, true>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
                            static_cast<long long>(read_count), static_cast<int>(n_groups), word_num, nq, q_tile, k, stride,
                            fault, d_content, ref_start, len, push_row, push_max, phase);
+#endif
     else if (k <= 15)
         hipLaunchKernelGGL((banded_asm_kernel<false, false>), grid, dim3(256), 0, stream,
                            static_cast<const unsigned char *>(d_workspace), d_peq, d_results,
@@ -943,6 +951,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     return BGSA_HIP_OK;
 }
 
+#if BGSA_AB_KERNELS
 template <typename T>
 int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, int len,
               int64_t read_count, int ref_start, int ref_end, int word_num, int k, hipStream_t stream)
@@ -963,6 +972,7 @@ int launch_t(const char *d_content, const uint32_t *d_peq, int8_t *d_results, in
     BGSA_HIP_TRY(hipGetLastError());
     return BGSA_HIP_OK;
 }
+#endif  // BGSA_AB_KERNELS
 
 }  // namespace
 
@@ -1002,6 +1012,10 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
         return BGSA_HIP_EUNSUPPORTED;
     }
     g_last_k = k;
+#if !BGSA_AB_KERNELS
+    if (banded_impl() >= 1 && banded_impl() <= 3) return ab_knob_refused("BGSA_BANDED_IMPL=c/s/p");
+    return launch_asm(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k, d_workspace, stream);
+#else
     if (banded_impl() == 2 && k <= 15)
         return launch_chunk(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end, word_num, k,
                             d_workspace, stream);
@@ -1013,6 +1027,7 @@ int launch_banded(const char *d_content, const uint32_t *d_peq, int8_t *d_result
                                   word_num, k, stream);
     return launch_t<uint64_t>(d_content, d_peq, d_results, read_len, read_count, ref_start, ref_end,
                               word_num, k, stream);
+#endif
 }
 
 }  // namespace bgsa

@@ -418,6 +418,20 @@ inline size_t blocked_carry_bytes(int ref_len, int n_chains)
     return static_cast<size_t>((ref_len + 31) / 32) * n_chains * kLanes * sizeof(uint32_t) * kWavesPerBlock * blocked_workgroups();
 }
 size_t long_state_bytes(int algo, int word_num);
+// Two flavours of the library are built from these sources (Makefile):
+//   libbgsa_hip.so     the kernels that are defaults, and the BitPAl score sets of BITPAL_SETS;
+//   libbgsa_hip_ab.so  (-DBGSA_AB_KERNELS=1, `make ab`) additionally every measured-and-not-adopted alternative that a
+//                      measurement knob can select — the compiler-scheduled kernels (BGSA_*_IMPL=c, long_kernels.hip), the
+//                      banded loops with the band held in place / straight-line rows (BGSA_BANDED_IMPL=p / s), the Myers
+//                      code-plane kernels below 29 words (BGSA_MYERS_PEQ_MAX_WORDS) and code-plane column blocks
+//                      (BGSA_MYERS_BLOCK_FORM=planes) — and the score sets of BITPAL_SETS_AB.
+// A knob that asks the default flavour for a kernel it does not carry fails loudly (ab_knob_refused), it is never ignored.
+#ifndef BGSA_AB_KERNELS
+#define BGSA_AB_KERNELS 0
+#endif
+// `what` names the knob as the caller set it; returns BGSA_HIP_EUNSUPPORTED with the error text set.
+int ab_knob_refused(const char *what);
+
 int launch_long(int algo, const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                 int read_len, int64_t read_count, int ref_start, int ref_end, int word_num, void *d_state,
                 hipStream_t stream);

@@ -12,7 +12,11 @@
 
 namespace bgsa {
 
-#include "_gen/bitpal_sets.inc"   // accessor declarations + kBitpalSets[] (generated)
+#if BGSA_AB_KERNELS
+#include "_gen/bitpal_sets_ab.inc"   // accessor declarations + kBitpalSets[] (generated): the sets of BITPAL_SETS_AB
+#else
+#include "_gen/bitpal_sets.inc"      // ... of BITPAL_SETS
+#endif
 
 int bitpal_set_count() { return static_cast<int>(sizeof(kBitpalSets) / sizeof(kBitpalSets[0])); }
 const BitpalSet *bitpal_set_at(int i) { return (i >= 0 && i < bitpal_set_count()) ? kBitpalSets[i]() : nullptr; }
@@ -63,9 +67,13 @@ int launch_bitpal(const BitpalSet *s, const char *d_content, const uint32_t *d_p
                   void *d_workspace, hipStream_t stream, int semi_global)
 {
     if (ref_end <= ref_start || read_count == 0) return BGSA_HIP_OK;
+#if BGSA_AB_KERNELS
     if (word_num > s->max_plain && bitpal_c_impl(s) && !semi_global)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_BITPAL, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);
+#else
+    if (word_num > s->max_plain && bitpal_c_impl(s) && !semi_global) return ab_knob_refused("BGSA_BITPAL_IMPL=c");
+#endif
     return s->launch(d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start, ref_end, word_num,
                      d_workspace, stream, semi_global);
 }

@@ -220,13 +220,25 @@ static size_t plan_workspace_bytes(const Plan &plan, int ref_len, int read_len, 
         const size_t blocked = static_cast<size_t>(blocked_stream_layout(ref_len, nullptr, nullptr)) * n_queries + 256 +
                                carries + 256;   // + the task counter
         // the A/B state-in-memory kernels (BGSA_MYERS_IMPL=c / BGSA_BITPAL_IMPL=c) keep the DP state here
+#if BGSA_AB_KERNELS
         const char *ab = getenv(algo == BGSA_ALGO_BITPAL ? "BGSA_BITPAL_IMPL" : "BGSA_MYERS_IMPL");
         const size_t in_memory = (ab && ab[0] == 'c') ? long_state_bytes(algo, (read_len + 31) / 32) : 0;
         return blocked > in_memory ? blocked : in_memory;
+#else
+        return blocked;
+#endif
     }
     if (algo == BGSA_ALGO_BANDED)  // the stream length depends on k: sized for the worst k
         return banded_stream_bound(ref_len) * n_queries + kTaskCounterBytes;
     return stream_stride(ref_len) * static_cast<size_t>(n_queries) + kTaskCounterBytes;   // bgsa_common.h "dynamic task handout"
+}
+
+int ab_knob_refused(const char *what)
+{
+    std::string msg = std::string(what) + " selects a kernel that only the A/B flavour of the library carries: build it with `make -C "
+                      "bgsa_amd/csrc ab` and point BGSA_HIP_LIB at libbgsa_hip_ab.so";
+    set_error_text(msg.c_str());
+    return BGSA_HIP_EUNSUPPORTED;
 }
 
 }  // namespace bgsa

@@ -958,6 +958,13 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         default: break;
         }
     }
+#if !BGSA_AB_KERNELS
+    if (myers_impl() == 1) return ab_knob_refused("BGSA_MYERS_IMPL=c");
+    if (semi_global) {
+        set_error_text("myers: no semi-global kernel for this word count");
+        return BGSA_HIP_EUNSUPPORTED;
+    }
+#else
     if (semi_global) {  // BGSA_MYERS_IMPL=c: the compiler-scheduled kernel, subjects up to 1024 bp (A/B reference)
         switch (pick_nw(word_num)) {
 #define BGSA_CASE(N)                                                                            \
@@ -976,6 +983,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
     if (word_num > myers_max_plain_words() && myers_impl() == 1)  // A/B: the state-in-memory C++ kernel
         return launch_long(BGSA_ALGO_MYERS, d_content, d_peq, d_results, ref_len, read_len, read_count, ref_start,
                            ref_end, word_num, d_workspace, stream);
+#endif
     if (word_num > myers_max_plain_words() && peq_blocks()) {
         int n_blocks = 0;
         switch (pick_peq_block_nw(word_num, &n_blocks)) {
@@ -988,6 +996,9 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         default: break;
         }
     }
+#if !BGSA_AB_KERNELS
+    if (word_num > myers_max_plain_words()) return ab_knob_refused("BGSA_MYERS_BLOCK_FORM=planes");
+#else
     if (word_num > myers_max_plain_words()) {
         int n_blocks = 0;
         switch (pick_block_nw(word_num, &n_blocks)) {
@@ -1001,6 +1012,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         default: break;
         }
     }
+#endif
     if (myers_impl() == 0) {
         if (word_num <= kPairMaxWords && pair_groups() == 2 && read_count >= 2 * kLanes) {   // short subjects: two groups per wave
             if (word_num == 1)
@@ -1026,13 +1038,22 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
     case N:                                                                                     \
         return launch_planes<N>(d_content, d_peq, d_results, ref_len, read_len, read_count,     \
                                 ref_start, ref_end, word_num, d_workspace, stream);
+#if BGSA_AB_KERNELS   // the code planes below 29 words: only under BGSA_MYERS_PEQ_MAX_WORDS (resident Peq planes measured faster)
             BGSA_PLANES_CASE(10) BGSA_PLANES_CASE(12) BGSA_PLANES_CASE(14) BGSA_PLANES_CASE(16)
             BGSA_PLANES_CASE(18) BGSA_PLANES_CASE(20) BGSA_PLANES_CASE(22) BGSA_PLANES_CASE(24)
-            BGSA_PLANES_CASE(26) BGSA_PLANES_CASE(28) BGSA_PLANES_CASE(30) BGSA_PLANES_CASE(32)
+            BGSA_PLANES_CASE(26) BGSA_PLANES_CASE(28)
+#endif
+            BGSA_PLANES_CASE(30) BGSA_PLANES_CASE(32)
 #undef BGSA_PLANES_CASE
         default: break;
         }
     }
+#if !BGSA_AB_KERNELS
+    if (myers_impl() == 1) return ab_knob_refused("BGSA_MYERS_IMPL=c");
+    if (myers_peq_max_words() != kPeqMaxWords) return ab_knob_refused("BGSA_MYERS_PEQ_MAX_WORDS");
+    set_error_text("myers: no kernel for this word count");
+    return BGSA_HIP_EUNSUPPORTED;
+#else
     switch (pick_nw(word_num)) {
 #define BGSA_CASE(N)                                                                            \
     case N:                                                                                     \
@@ -1046,6 +1067,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
         set_error_text("myers: no kernel for this word count");
         return BGSA_HIP_EUNSUPPORTED;
     }
+#endif
 }
 
 }  // namespace bgsa

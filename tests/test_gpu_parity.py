@@ -644,6 +644,7 @@ def test_resident_bucket_rewritten_behind_the_librarys_back_is_not_scored_stale(
         assert np.array_equal(fine(), want_b) and stale() == s0 + 1          # uploaded once, rows scored from the new copy
         # --- and back, this time the fine seam sees it first: every thread's last row (the lock-free path) and the
         # cached rows belong to the old content and must not be served
+        y[:] = 0                                                             # the preprocess ORs bits in (cal_cpu.c:273)
         L.hip_handle_reads(ctypes.byref(seq_a), y.ctypes.data, wn, 0, n)     # y := bucket A (y itself is registered too)
         ctypes.memmove(x.ctypes.data, y.ctypes.data, x.nbytes)
         assert np.array_equal(fine(), want_a) and stale() == s0 + 2
@@ -654,6 +655,7 @@ def test_resident_bucket_rewritten_behind_the_librarys_back_is_not_scored_stale(
         sampled = {(j * (lines - 1)) // 33 for j in range(34)}
         g_lines = gw * 4 // 64
         victim = next(g for g in range(1, n // 64) if not any(g * g_lines <= ln < (g + 1) * g_lines for ln in sampled))
+        y[:] = 0
         L.hip_handle_reads(ctypes.byref(seq_b), y.ctypes.data, wn, 0, n)     # y := bucket B
         assert L.bgsa_hip_set_strict_resident(1) == 0
         assert np.array_equal(coarse(), want_a)                              # strict mode takes its host copy of the range here
@@ -958,7 +960,20 @@ def _related(oracle, q, n, slen, seed):
     return s
 
 
-@pytest.mark.parametrize("scores", B.score_sets() if B.LIB_PATH.exists() else [])
+def _sets_under_test():
+    """The compiled score sets; under BGSA_TEST_SETS=ab_only (the child pytest of test_score_sets_of_the_ab_flavour, which
+    loads libbgsa_hip_ab.so) only those the default flavour does not carry."""
+    import os
+    if not B.LIB_PATH.exists():
+        return []
+    sets = B.score_sets()
+    if os.environ.get("BGSA_TEST_SETS") == "ab_only":
+        default = {(2, -3, -5), (1, -1, -2), (1, -4, -2), (10, -9, -15)}
+        sets = [x for x in sets if x not in default]
+    return sets
+
+
+@pytest.mark.parametrize("scores", _sets_under_test())
 @pytest.mark.parametrize("qlen,slen", [(150, 150), (1, 1), (40, 70), (97, 33), (250, 256), (31, 225), (150, 257),
                                        (90, 300), (300, 600), (64, 513), (33, 1100)])
 def test_bitpal_score_sets_vs_needleman_wunsch(oracle, scores, qlen, slen):
@@ -1021,7 +1036,7 @@ def test_uncompiled_score_set_is_refused(oracle):
 
 
 # ---- semi-global BitPAl (generator option -s): DP definition as the checker ------------------------------
-@pytest.mark.parametrize("scores", B.score_sets() if B.LIB_PATH.exists() else [])
+@pytest.mark.parametrize("scores", _sets_under_test())
 @pytest.mark.parametrize("qlen,slen", [(60, 150), (150, 150), (97, 33), (1, 1), (20, 256), (100, 300), (50, 1000), (300, 777)])
 def test_bitpal_semiglobal_vs_dp(oracle, scores, qlen, slen):
     q = oracle.gen_reads(300 + qlen, 4, qlen)
@@ -1299,9 +1314,62 @@ def test_measurement_knobs_do_not_change_results(env):
     import sys
     from pathlib import Path
     root = Path(B.__file__).resolve().parent.parent
+    env = dict(env)
+    if _needs_ab_flavour(env):      # a kernel only the A/B flavour of the library carries (make -C bgsa_amd/csrc ab)
+        assert B.LIB_AB_PATH.exists(), "libbgsa_hip_ab.so is not built"
+        env["BGSA_HIP_LIB"] = str(B.LIB_AB_PATH)
     p = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, str(root)], env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "knobs ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def _needs_ab_flavour(env):
+    return (any(env.get(k, "")[:1] == "c" for k in ("BGSA_MYERS_IMPL", "BGSA_BITPAL_IMPL", "BGSA_BANDED_IMPL"))
+            or env.get("BGSA_BANDED_IMPL", "")[:1] in ("s", "p") or "BGSA_MYERS_PEQ_MAX_WORDS" in env
+            or env.get("BGSA_MYERS_BLOCK_FORM") == "planes")
+
+
+@pytest.mark.parametrize("env,algo,length,k", [({"BGSA_MYERS_IMPL": "c"}, 0, 150, 0), ({"BGSA_BANDED_IMPL": "s"}, 1, 150, 8),
+                                                ({"BGSA_BANDED_IMPL": "p"}, 1, 150, 8), ({"BGSA_BANDED_IMPL": "c"}, 1, 150, 8),
+                                                ({"BGSA_MYERS_PEQ_MAX_WORDS": "8"}, 0, 400, 0),
+                                                ({"BGSA_MYERS_MAX_PLAIN_WORDS": "8", "BGSA_MYERS_BLOCK_FORM": "planes"}, 0, 400, 0)])
+def test_default_library_refuses_knobs_for_kernels_it_does_not_carry(env, algo, length, k):
+    """The default flavour ships the kernels that are defaults; a measurement knob that selects one of the alternatives must
+    fail loudly there (and name the A/B build), never fall back to another kernel in silence."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(B.__file__).resolve().parent.parent
+    script = ("import sys; sys.path.insert(0, sys.argv[1])\n"
+              "import bgsa_amd as B, oracle as O\n"
+              f"q = O.gen_reads(1, 3, {length}); s = O.gen_reads(2, 128, {length})\n"
+              "try:\n"
+              f"    B.align_all_pairs(q, s, algo={algo}, k={k})\n"
+              "except B.BgsaHipError as e:\n"
+              "    print('refused:', e)\n")
+    p = subprocess.run([sys.executable, "-c", script, str(root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "refused:" in p.stdout and "A/B flavour" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_score_sets_of_the_ab_flavour(oracle):
+    """The default flavour compiles four BitPAl score sets; the three others of round 3 (0/-1/-1 as a BitPAl body, 1/-3/-2,
+    5/-4/-10) ship in the A/B flavour.  Their global and semi-global suites run here against that library, in a child pytest."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(B.__file__).resolve().parent.parent
+    assert B.LIB_AB_PATH.exists(), "libbgsa_hip_ab.so is not built"
+    env = dict(os.environ, BGSA_HIP_LIB=str(B.LIB_AB_PATH), BGSA_TEST_SETS="ab_only")
+    p = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "test_bitpal_score_sets_vs_needleman_wunsch or test_bitpal_semiglobal_vs_dp or "
+                        "test_bitpal_edit_scores_agree_with_the_myers_kernel"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and " failed" not in p.stdout
+    n = int(p.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
+    assert n >= 3 * (11 + 8) + 1, p.stdout[-500:]          # three sets x (11 global + 8 semi-global cases) + the edit-set check
 
 
 # ---- the streamed gather on one GPU: the side stream moves block i while the compute stream scores block i+1 ----
