@@ -973,8 +973,9 @@ static size_t row_arena_slots_for(size_t size)
 {
     const size_t slot = (size + 4095) & ~size_t(4095);
     std::lock_guard<std::mutex> lock(g_arena.mu);
-    if (g_arena.base && g_arena.slot_bytes) return size <= g_arena.slot_bytes ? g_arena.n_slots : 0;
-    if (g_arena.tried) return 0;      // no arena could be had: rows take the heap / staged path
+    if (g_arena.base && g_arena.slot_bytes && size <= g_arena.slot_bytes) return g_arena.n_slots;
+    // no arena (yet, or none could be had, or carved for smaller rows): such rows take the heap / staged path, which
+    // the cache's byte budget bounds; the carving rule stands in for the count
     return std::min(kRowArenaBytes, std::max(size_t(64) << 20, 512 * slot)) / std::max<size_t>(slot, 1);
 }
 static bool row_arena_too_small(size_t size)
