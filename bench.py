@@ -422,7 +422,7 @@ def preflight(dist, dev, rank, world, local_rank):
         info["peer_access"] = [bool(j == dev.index or torch.cuda.can_device_access_peer(dev.index, j)) for j in range(n_dev)]
     except Exception as e:
         info["peer_access_error"] = repr(e)
-    if dist is not None and world > 1:
+    if dist is not None:      # also with one rank under torchrun: the collective still runs on the RCCL backend
         mb = float(os.environ.get("BGSA_BENCH_PREFLIGHT_MB", "64"))
         n = max(1, int(mb * (1 << 20)))
         try:

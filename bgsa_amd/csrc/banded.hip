@@ -919,7 +919,8 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
         if (banded_dynamic_tasks() && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
             counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
             BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
-            grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
+            const int resident = G == 2 ? persistent_blocks_for(banded_cut_kernel<2, true>) : persistent_blocks_for(banded_cut_kernel<1, true>);
+            grid = dim3(static_cast<unsigned>(blocks < resident ? blocks : resident), 1u);
         }
         auto kernel = G == 2 ? (counter ? banded_cut_kernel<2, true> : banded_cut_kernel<2, false>)
                              : (counter ? banded_cut_kernel<1, true> : banded_cut_kernel<1, false>);

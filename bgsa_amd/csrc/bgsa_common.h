@@ -350,6 +350,32 @@ inline int persistent_blocks()
     }();
     return n;
 }
+// ... of ONE kernel: as many workgroups as the device really keeps resident for it (hipOccupancyMaxActiveBlocksPerMultiprocessor:
+// a kernel at two waves per SIMD holds two workgroups per CU, not eight).  Workgroups beyond that would start only after the
+// resident waves have drained the counter, each run its one statically assigned first task and leave: a static tail, the
+// imbalance the counter is there to remove.  Per device and kernel; cached.
+template <typename Kernel>
+inline int persistent_blocks_for(Kernel kernel, size_t dynamic_lds = 0)
+{
+    struct Entry { int dev; const void *fn; size_t lds; int blocks; };
+    static thread_local Entry last{-1, nullptr, 0, 0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return persistent_blocks();
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    if (last.dev == dev && last.fn == fn && last.lds == dynamic_lds) return last.blocks;
+    int cus = 256, per_cu = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dynamic_lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 8;
+    }
+    if (const char *e = getenv("BGSA_PERSISTENT_PER_CU")) {      // measurement knob: workgroups per CU of the persistent grids
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8) per_cu = v;
+    }
+    last = Entry{dev, fn, dynamic_lds, cus * (per_cu < 8 ? per_cu : 8)};
+    return last.blocks;
+}
 // The counter of a launch whose streams take stream_bytes of the workspace.
 inline unsigned *task_counter_in(void *d_workspace, size_t stream_bytes)
 {

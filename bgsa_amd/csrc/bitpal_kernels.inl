@@ -380,7 +380,8 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
     if (plan.dynamic) {
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
         counter = task_counter_in(d_workspace, stream_stride(ref_len) * static_cast<size_t>(nq));
-        grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
+        const int resident = semi ? persistent_blocks_for(bitpal_asm_kernel<NW, true, true>) : persistent_blocks_for(bitpal_asm_kernel<NW, false, true>);
+        grid = dim3(static_cast<unsigned>(blocks < resident ? blocks : resident), 1u);
     }
     if (int rc = launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)) return rc;
     unsigned *fault = nullptr;

@@ -1280,7 +1280,7 @@ def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int], bool]:
     most 12; measured for 2/-3/-5: 9-11 words at two waves per SIMD run at 27.8-28.5 TCUPS against 24.5 for the same
     subjects as column blocks).  Column-block kernels for longer subjects: the four widths up to W <= 8 words in the
     per-chain carry form (a block also carries 2 x chains carry words — round 2's only form), or, for score sets
-    with so many chains that not even a one-word block fits that way (match - mismatch >= ~12: chains = 1 + 2 (M - I - 1) +
+    with so many chains that not even a one-word block fits that way (match - mismatch >= ~20: chains = 1 + (M - I - 1) +
     bits(M - 2G)), in the PACKED carry form (rows_ir.make_blocked_packed: ceil(chains / 32) words per direction
     whatever the set).  What bounds the domain then is the row body itself: it keeps M - I one-hot class masks and as
     many incoming-value masks of one word alive at once, so a one-word body needs about 2 (M - I) + bits(M - 2G) + 16
@@ -1316,10 +1316,13 @@ def bitpal_widths(sc: R.BitpalScores) -> tuple[list[int], list[int], bool]:
             f"bits(match - 2 gap) = {sc.nb} planes are over what a wave can hold")
     plain = max(fits_plain)
     fits_block = fitting(block_regs, BITPAL_BLOCK_VGPR_BUDGET, 8)
-    if fits_block:
+    fits_packed = fitting(packed_regs, BITPAL_VGPR_BUDGET, 8)
+    # the per-chain form (carry words exchanged every 32 rows) wherever it reaches four-word blocks; below that the packed
+    # form if it offers WIDER blocks (fewer blocks per subject): with one chain per class (round 4) 10/-9/-15 has 25 chains
+    # and one- and two-word blocks fit per chain, three-word ones packed
+    if fits_block and (not fits_packed or max(fits_block) >= min(4, max(fits_packed))):
         wide = max(fits_block)
         return list(range(1, plain + 1)), list(range(max(1, wide - 3), wide + 1)), False
-    fits_packed = fitting(packed_regs, BITPAL_VGPR_BUDGET, 8)
     if not fits_packed:
         raise BitpalDomainError(
             f"BitPAl {sc.match}/{sc.mismatch}/{sc.gap}: no column-block kernel fits: one word needs {packed_regs(1)} VGPRs "

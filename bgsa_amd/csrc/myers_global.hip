@@ -650,7 +650,9 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     if (plan.dynamic) {
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
         counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
-        grid = dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks()), 1u);
+        int resident = persistent_blocks();
+        if constexpr (NW <= 8) resident = persistent_blocks_for(myers_global_asm_kernel<NW, G, true>);
+        grid = dim3(static_cast<unsigned>(blocks < resident ? blocks : resident), 1u);
     }
     if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)
                         : launch_pack_queries(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter))
@@ -731,7 +733,8 @@ int launch_planes(const char *d_content, const uint32_t *d_peq, int16_t *d_resul
                            nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault);
     else if (dynamic) {
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
-        hipLaunchKernelGGL((myers_global_planes_kernel<NW, true>), dim3(static_cast<unsigned>(blocks < persistent_blocks() ? blocks : persistent_blocks())),
+        const int resident = persistent_blocks_for(myers_global_planes_kernel<NW, true>);
+        hipLaunchKernelGGL((myers_global_planes_kernel<NW, true>), dim3(static_cast<unsigned>(blocks < resident ? blocks : resident)),
                            dim3(256), 0, stream, static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                            read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
                            nq, q_tile, static_cast<int>(stream_stride(ref_len)), fault, counter);

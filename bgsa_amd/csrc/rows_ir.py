@@ -1211,7 +1211,7 @@ class BitpalScores:
     @property
     def planes(self) -> int: return self.nb                       # unsigned u: no sign plane
     @property
-    def chains(self) -> int: return 1 + 2 * (self.K - 1) + self.nb
+    def chains(self) -> int: return 1 + (1 if BITPAL_ONE_CHAIN else 2) * (self.K - 1) + self.nb
     @property
     def tag(self) -> str:
         f = lambda v: f"m{-v}" if v < 0 else f"{v}"
@@ -1224,6 +1224,12 @@ class BitpalScores:
 
 BITPAL_DEFAULT = BitpalScores(2, -3, -5)
 BITPAL_SCHEDULE_WINDOW = int(__import__('os').environ.get('BGSA_GEN_BITPAL_WINDOW', '48'))   # 0 = program order (A/B)
+# build-time A/B switches of round 4's two rewrites of the row body (see bitpal_scores_body; scripts/r04_bitpal_ab.sh,
+# profiles/r04_bitpal_ab.txt, 10k x 1M x 150 bp on one box): reading "u <= D" off its plane — one instruction fewer — measured
+# 6,893 -> 6,854 ms and is on; one addition chain per class instead of two — same count, 13 -> 9 chains — measured 6,893 -> 6,949 ms
+# (and the chip held a lower clock under it) and is OFF
+BITPAL_ONE_CHAIN = __import__('os').environ.get('BGSA_GEN_BITPAL_ONE_CHAIN', '0') != '0'
+BITPAL_INLINE_LE = __import__('os').environ.get('BGSA_GEN_BITPAL_INLINE_LE', '1') != '0' 
 
 
 class _Bool:
@@ -1295,8 +1301,8 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     """(Memoised: callers treat the returned Body as read-only.)  Row body for `nw` words.  State S[w*B + i] = plane i (weight 2^i) of the UNSIGNED value u of word
     w's 32 columns, B = sc.planes = bits(C) (the reference keeps the two's complement of -u in one more
     plane, align_core.c:191-214; the unsigned form saves that plane and four instructions per word).
-    E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed shift and its
-    run, then the B plane shifts — sc.chains in all."""
+    E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed shift and its run (one chain
+    for both under BGSA_GEN_BITPAL_ONE_CHAIN=1, measured slower), then the B plane shifts — sc.chains in all."""
     B, C, D, K = sc.planes, sc.C, sc.D, sc.K
     b = Body()
     U = lambda w, i: f"S{w * B + i}"
@@ -1305,6 +1311,7 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     W = range(nw)
     z = {}      # (value of u, word) -> one-hot mask name
     anym = {}   # word -> mismatch columns whose u <= D
+    le_plane = {}   # word -> the ONE plane p with "u <= D  <=>  ~p" (D + 1 a power of two): no mask of its own is built
     dv = {}     # (class offset c, word) -> columns whose incoming v is C - c (c = 0: or a match)
 
     # ---- decode the u classes the seeds need, the "u <= D" mask, and the top-class run ----------
@@ -1356,7 +1363,9 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
                     else:
                         cur = bx.op3(lambda x0, rv, _r, b0=b0: step(rv, x0, b0), planes[i], cur, cur, "le")
                     i += 1
-            if cur is None:   # the comparison is just "~plane[first]"
+            if cur is None and BITPAL_INLINE_LE:   # the comparison is just "~plane[first]": max_planes() reads that plane itself
+                le_plane[w] = planes[first]
+            elif cur is None:
                 anym[w] = bx.op3(lambda p, e, _e: ~p & ~e, planes[first], E(w), E(w), "any")
             else:
                 anym[w] = bx.op3(lambda le, e, _e: le & ~e, cur, E(w), E(w), "any")
@@ -1366,10 +1375,21 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
         dv[0, w] = b.BITOP3(t("dvtop", w), t("sum", w), t("run", w), E(w), lambda s, r, e: (s ^ r) | e)
 
     def shifted_run(seed_name, c):
+        # The seeds act one column up and spread over the run behind them: (seed << 1) + run.  A seed sits on a column with
+        # u > 0, a run column has u = 0, so the two are disjoint and (seed << 1) + run = seed + (seed | run): ONE addition
+        # with carry across the words instead of a shift chain and an addition chain (13 -> 9 chains for 2/-3/-5, same
+        # instruction count).  Built, bit-exact, measured 0.8 % SLOWER on the full config 4: the A/B alternative.
+        if not BITPAL_ONE_CHAIN:      # round 3's form: a shift chain, then an addition chain
+            for w in W:
+                (b.ADD_CO if w == 0 else b.ADDC)(t(seed_name, w), t(seed_name, w), t(seed_name, w))
+            for w in W:
+                (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(seed_name, w), t("run", w))
+                dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
+            return
         for w in W:
-            (b.ADD_CO if w == 0 else b.ADDC)(t(seed_name, w), t(seed_name, w), t(seed_name, w))
+            b.OR(t(f"sr{c}", w), t(seed_name, w), t("run", w))
         for w in W:
-            (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(seed_name, w), t("run", w))
+            (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(f"sr{c}", w), t(seed_name, w))
             dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
 
     # ---- classes C-1 .. D+1: value C-c appears where an incoming class C-x meets u = c-x ----------
@@ -1465,6 +1485,14 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     def max_planes(w):
         for i in range(B):
             cb, db = 0xFF * ((C >> i) & 1), 0xFF * ((D >> i) & 1)
+            if w in le_plane:      # "u <= D" is the complement of one plane: read it directly (one instruction per word saved)
+                p = le_plane[w]
+                if U(w, i) == p:
+                    b.BITOP3(t(f"g{i}", w), p, p, E(w), lambda u, _u, e, cb=cb, db=db: (cb & e) | (db & ~u & ~e) | (u & ~e))
+                else:
+                    b.BITOP3(t(f"g{i}", w), U(w, i), p, E(w),
+                             lambda u, p_, e, cb=cb, db=db: (cb & e) | (db & ~p_ & ~e) | (u & p_ & ~e))
+                continue
             b.BITOP3(t(f"g{i}", w), U(w, i), anym[w], E(w),
                      lambda u, a, e, cb=cb, db=db: (cb & e) | (db & a & ~e) | (u & ~a & ~e))
 

@@ -343,10 +343,14 @@ class ShardedAligner:
         local = self.score_fn(q, subjects_all[mine.start: mine.start + mine.count])
         if not gather:
             return local, shards
+        if self.dist is None or self.world == 1:
+            # one rank: its tile IS the result — no block buffers, no copies (device_blocks = the one device's block, flat)
+            return (local if layout == "row_major" else local.reshape(-1)), shards
         # the gather is the streamed one with a single block of all the queries: every peer's tile goes straight
-        # into its segment of root's buffer (nothing padded to the widest shard, nothing staged `world` times)
-        gs = ScoreGatherStream(self.dist, local.device, [s.count for s in shards], local.dtype, max(int(local.shape[0]), 1), layout)
+        # into its segment of root's buffer (nothing padded to the widest shard, nothing staged `world` times).
+        # depth 1: one block, one buffer; the stream object is dropped behind this call, so the buffer is handed out as is
+        gs = ScoreGatherStream(self.dist, local.device, [s.count for s in shards], local.dtype, max(int(local.shape[0]), 1), layout,
+                               depth=1)
         gs.submit(local)
         gs.drain()
-        out = gs.last_block()
-        return (out.clone() if out is not None else None), shards
+        return gs.last_block(), shards

@@ -121,6 +121,26 @@ def test_bench_line_survives_a_gather_that_never_finishes():
     assert "did not finish" in r["gather"]["error"] and r["gather_ok"] is False
 
 
+def test_bench_line_under_torchrun_with_one_rank_goes_through_rccl():
+    """What can be run of the RCCL path on a one-GPU box: bench.py exactly as the driver starts it (torch.distributed.run, backend
+    nccl = RCCL, init_process_group with device_id), world size 1 — the process group's init, the barriers, the query broadcast,
+    the pre-flight all_gather, all_gather_object and the all_reduce of the timing all execute on the RCCL backend (with one
+    rank they move no byte between devices: that stays the SCALE run's to show).  The line must say rccl_ok = true."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BGSA_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--nq", "300", "--ns", "64000", "--no-cpu-baseline", "--no-total", "--no-other-configs"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["rccl_ok"] is True and r["n_gpus"] == 1 and r["value"] > 0 and "watchdog" not in r
+    assert r["ranks_seen"] == 1 and r["ranks"][0]["peer_access"] and r["ranks"][0]["peer_access"][0] is True
+    assert r["preflight"]["all_gather"]["content_ok"] is True
+
+
 def test_bench_line_when_a_rank_never_joins():
     """The likeliest first failure on a real node is a hang in RCCL's init.  One rank never reaches init_process_group:
     the whole-run watchdog (armed before the group exists) ends the run within its limit, rank 0 prints a parseable stub

@@ -324,11 +324,12 @@ def test_bitpal_any_scores_column_blocks(oracle, scores, qlen, slen, nwb):
 
 def test_bitpal_default_scores_instance():
     # 2/-3/-5: u in 0..12 on four unsigned planes (the reference keeps -u in five, align_core.c:191-214),
-    # five value classes above the mismatch class, thirteen carry chains
+    # five value classes above the mismatch class, thirteen carry chains, 68 instructions per word (69 until round 4:
+    # "u <= 7" is read off plane 3 instead of being built as a mask)
     sc = R.BITPAL_DEFAULT
     assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (4, 13, 12, 7, 5)
     assert sc.weights() == (1, 2, 4, 8)
-    assert R.bitpal_body(1).valu_count() == 69
+    assert R.bitpal_body(1).valu_count() == 68
 
 
 def test_bitpal_edit_scores_equal_negated_myers(oracle):
@@ -350,7 +351,7 @@ def test_bitpal_set_generator_picks_widths_that_fit(tmp_path):
         plain, blocks, _packed = G.bitpal_widths(sc)
         assert plain[0] == 1 and plain == list(range(1, plain[-1] + 1)) and plain[-1] <= 12 and blocks[-1] <= 8
         assert sc.planes * plain[-1] + 5 * plain[-1] + R.bitpal_body(plain[-1], sc).allocate_temps()[1] <= G.BITPAL_VGPR_BUDGET
-    assert G.bitpal_widths(R.BITPAL_DEFAULT) == (list(range(1, 12)), [5, 6, 7, 8], False)   # 352 bp in registers (2 waves/SIMD)
+    assert G.bitpal_widths(R.BITPAL_DEFAULT) == (list(range(1, 13)), [5, 6, 7, 8], False)   # 384 bp in registers (2 waves/SIMD)
 
 
 # ---- semi-global BitPAl (generator option -s): same row body, other first row and last-row maximum ----
