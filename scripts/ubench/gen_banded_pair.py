@@ -47,6 +47,11 @@ def pair(g, x2="align", win="align"):
     out = []
     if win == "align":
         out += [f"v_alignbit_b32 {r['wl']}, {r['e1']}, {r['e0']}, {S_SH}", f"v_alignbit_b32 {r['wh']}, {r['e2']}, {r['e1']}, {S_SH}"]
+    elif win == "align_v":  # the shift amount in a VGPR (v12), kept by one more fast-class instruction per row
+        out += [f"v_alignbit_b32 {r['wl']}, {r['e1']}, {r['e0']}, v12", f"v_alignbit_b32 {r['wh']}, {r['e2']}, {r['e1']}, v12",
+                f"v_xor_b32 {r['q1']}, 1, {r['q1']}"]
+    elif win == "align_i":  # HYPOTHETICAL: immediate shift amounts (would need one body per row position)
+        out += [f"v_alignbit_b32 {r['wl']}, {r['e1']}, {r['e0']}, 5", f"v_alignbit_b32 {r['wh']}, {r['e2']}, {r['e1']}, 5"]
     elif win == "one":      # second row of a token: the high half is the previous one shifted (bit 63 is outside every band)
         out += [f"v_alignbit_b32 {r['wl']}, {r['wh']}, {r['wl']}, 1", f"v_lshrrev_b32 {r['wh']}, 1, {r['wh']}"]
     else:                   # hypothetical: fast-class stand-ins
@@ -104,6 +109,9 @@ UNROLL = 8
 KERNELS = [
     ("pair", pair(0), 1),
     ("pair_zip2", zip2(lambda g: pair(g)), 2),
+    ("pair_vsh", pair(0, win="align_v"), 1),                          # window funnel shifts by a VGPR instead of an SGPR
+    ("pair_vsh_zip2", zip2(lambda g: pair(g, win="align_v")), 2),
+    ("pair_ish", pair(0, win="align_i"), 1),
     ("pair_x2fast", pair(0, x2="fast"), 1),
     ("pair_x2fast_zip2", zip2(lambda g: pair(g, x2="fast")), 2),
     ("pair_win1", pair(0, win="one"), 1),
