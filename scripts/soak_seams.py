@@ -105,6 +105,35 @@ def main() -> int:
                         ok = False
                         break
                 done["align"] += len(order)
+            # every third case: the registered bucket is overwritten behind the library's back — another preprocessed
+            # bucket memmove'd over it, no call tells the library — and both seams must score the NEW content
+            # (every scoring call fingerprints the resident range)
+            if ok and case % 3 == 0:
+                s2 = O.gen_reads(int(rng.integers(1 << 30)), n, slen)
+                s2[:rel, :m] = O.mutate(q[np.arange(rel) % nq][:, :m], rng.integers(0, 10, rel), int(rng.integers(1 << 30)))
+                want2 = fn(q, s2[:check_cols])
+                sbuf2 = B.rows_to_buffer(s2)
+                seq2 = B.SeqT(len=slen, size=sbuf2.size, count=n, extra_size=0, extra_count=0, content=sbuf2.ctypes.data)
+                peq2 = np.zeros(gw * groups, dtype=np.uint32)
+                L.hip_handle_reads(ctypes.byref(seq2), peq2.ctypes.data, wn, 0, n)
+                before = ctypes.c_uint64()
+                L.bgsa_hip_stale_ranges(ctypes.byref(before))
+                ctypes.memmove(peq.ctypes.data, peq2.ctypes.data, peq2.nbytes)
+                fine_first = rng.random() < 0.5
+                for which in (("fine", "coarse") if fine_first else ("coarse", "fine")):
+                    if which == "coarse":
+                        out[:] = 99
+                        L.hip_cal_align_score(qblock, peq.ctypes.data, out.ctypes.data, qlen, nq, slen, n, lo, hi, wn, 27, None)
+                        ok = ok and np.array_equal(out[: hi - lo, :check_cols], want2[lo:hi])
+                    else:
+                        res = np.zeros(n, dtype=dtype)
+                        for i in order[:8]:
+                            L.align_hip(qblock + int(i) * (qlen + 1), peq.ctypes.data, qlen, slen, wn, groups, 0, res.ctypes.data, None)
+                            ok = ok and np.array_equal(res[:check_cols], want2[i])
+                after = ctypes.c_uint64()
+                L.bgsa_hip_stale_ranges(ctypes.byref(after))
+                ok = ok and after.value == before.value + 1      # detected once, by whichever seam came first
+                done["rewritten"] = done.get("rewritten", 0) + 1
             if not ok:
                 print(f"MISMATCH case {case}: algo {algo} k {k} qlen {qlen} slen {slen} nq {nq} groups {groups} pinned {pinned} window {lo}:{hi}", flush=True)
                 return 1
