@@ -111,6 +111,13 @@ def fixtures():
         q = O.gen_reads(0xB65A0800 + length, 6, length)
         s = planted(q, 48, 12, 80 + length, 0xB65A1800 + length)
         yield f"f8_banded_k8_len{length}", "banded_cpu", 8, q, s
+    # F8b (round 4): the thresholds that run the funnel-shift rows — 13 and 15 on one 32-bit word, 24 and the reference's
+    # default 31 on a register pair — on pairs with up to 3k edits, so that both outcomes (a distance, 127) are frequent.
+    # Lengths as above: 150 mod 64 = 22 rules 150 bp out for k >= 22.
+    for length, k in ((150, 13), (150, 15), (250, 24), (250, 31), (128, 31)):
+        q = O.gen_reads(0xB65A0880 + length + k, 8, length)
+        s = planted(q, 192, 3 * k, 88 + length + k, 0xB65A1880 + length + k)
+        yield f"f8_banded_k{k}_len{length}", "banded_cpu", k, q, s
     # F9: qlen != slen (non-banded only; banded is degenerate there)
     for ql, sl in ((140, 150), (150, 140), (100, 200), (33, 31)):
         q = O.gen_reads(0xB65A0900 + ql, 8, ql)

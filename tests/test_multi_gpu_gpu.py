@@ -65,15 +65,15 @@ def test_two_ranks_hip_compute_and_streamed_gather(tmp_path, oracle, algo, layou
     assert np.array_equal(got, np.concatenate(parts))
 
 
-def _bench_two_ranks(extra_env, extra_args=(), want_rc=0):
+def _bench_two_ranks(extra_env, extra_args=(), want_rc=0, ranks=2):
     """bench.py exactly as the driver starts it for N = 2, except that both ranks share this box's one card and the
     collectives go through gloo (BGSA_BENCH_SAME_GPU / BGSA_BENCH_BACKEND: a rehearsal of the code path, not a
     measurement)."""
     import json
     import subprocess
     env = dict(os.environ, BGSA_BENCH_SAME_GPU="1", BGSA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
            "--nq", "300", "--ns", "64000", *extra_args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert (p.returncode == 0) if want_rc == 0 else (p.returncode != 0), p.stdout[-2000:] + p.stderr[-2000:]
@@ -111,6 +111,19 @@ def test_bench_line_for_two_ranks(config):
     assert [x["rank"] for x in r["ranks"]] == [0, 1] and r["ranks_seen"] == 2
     assert all(x["kernel_ms"] > 0 and x["device"] for x in r["ranks"]) and r["ranks"][0]["pid"] != r["ranks"][1]["pid"]
     assert r["config"]["kernel_source_id"] and len(r["config"]["kernel_source_id"]) == 16
+
+
+def test_bench_line_for_four_ranks_weak_and_strong():
+    """Four ranks on the one card (the most this box allows beside the test process): config 2's weak-scaling shape with three
+    peers streaming their tiles to rank 0, and the strong leg's plan_shards cut of ONE bucket into four slices."""
+    r = _bench_two_ranks({}, ("--config", "2"), ranks=4)
+    assert r["n_gpus"] == 4 and r["ranks_seen"] == 4 and [x["rank"] for x in r["ranks"]] == [0, 1, 2, 3]
+    assert r["config"]["subjects_total"] == 4 * 64000 and r["gather_ok"] is True
+    assert r["gather"]["bytes_to_root_per_block"] == 3 * 64000 * 100 * 2
+    st = r["strong"]
+    assert "error" not in st, st
+    assert [x["subjects"] for x in st["ranks"]] == [16000] * 4 and st["subjects_total"] == 64000
+    assert st["gather"]["bytes_to_root_per_block"] == 3 * 16000 * 100 * 2 and st["gather"]["root_blocks_checked"] >= 3
 
 
 def test_bench_line_survives_a_gather_that_never_finishes():
