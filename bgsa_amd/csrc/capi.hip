@@ -778,11 +778,14 @@ struct ResidentRange {
 // that builds Peq itself and forgets bgsa_hip_bucket_resident) must not be scored from the stale device copy in silence
 // (SURVEY 8(b) "Ownership": the callee keeps no state between calls; the KNC precedent, BGSA_KNC/cal_mic.c:348-356,
 // justifies residency, not silence).  Every scoring call therefore fingerprints the host range it is about to use —
-// kFingerprintLines cache lines at fixed positions, first and last among them: a few hundred nanoseconds once the lines
-// are in the calling core's cache — and a range whose fingerprint changed is uploaded again (its cached rows dropped).
+// kFingerprintLines cache lines, the first, the last and a golden-ratio (Weyl) sequence of positions in between: a few
+// hundred nanoseconds once the lines are in the calling core's cache — and a range whose fingerprint changed is uploaded
+// again (its cached rows dropped).  The positions must not be an arithmetic progression: a stride of range / n lines is,
+// for n - 1 groups, the group size itself, and every sample then lands in the same plane and word of its group — the last
+// word of the class-N plane, all zeros in every bucket (found by scripts/soak_seams.py: 33 groups, 34 samples).
 // A rewrite that changes none of the sampled lines is only caught by the full comparison of
 // BGSA_HIP_STRICT_RESIDENT=1 / bgsa_hip_set_strict_resident(1), which keeps a host copy of what was uploaded.
-static constexpr size_t kFingerprintLines = 34;
+static constexpr size_t kFingerprintLines = 66;
 static uint64_t range_fingerprint(const unsigned char *p, size_t bytes)
 {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
@@ -793,10 +796,12 @@ static uint64_t range_fingerprint(const unsigned char *p, size_t bytes)
         return h;
     }
     const size_t n = std::min(lines, kFingerprintLines);
+    uint64_t weyl = 0;
     for (size_t j = 0; j < n; j++) {
-        // evenly spread over the range; with a group's five class planes 4 x word_num lines each, about a fifth of the
-        // samples fall into the plane of a class no read contains (all zeros in every bucket) — the others tell buckets apart
-        const size_t line = (j * (lines - 1)) / (n - 1);
+        // quasi-random over the range: about a fifth of the samples fall into the plane of a class no read contains (all
+        // zeros in every bucket), the others land in different planes, words and lanes of different groups
+        weyl += 0x9E3779B97F4A7C15ull;
+        const size_t line = j == 0 ? 0 : (j == 1 ? lines - 1 : static_cast<size_t>((static_cast<unsigned __int128>(weyl) * lines) >> 64));
         uint64_t w[8];
         memcpy(w, p + line * 64, 64);
         for (uint64_t x : w) mix(x);

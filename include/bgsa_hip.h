@@ -161,8 +161,8 @@ int bgsa_hip_set_auto_resident(int on);
 /* A resident range rewritten behind the library's back.  The contract above asks the caller to say so; when it does
  * not (a memcpy of a saved bucket over the registered buffer, a host that fills Peq itself), the library still does
  * not score from the stale device copy in silence: every scoring call — hip_cal_align_score, and align_hip on its
- * locked and its lock-free path — fingerprints the host range (34 cache lines at fixed positions, first and last
- * among them) and uploads the range again when the fingerprint differs from the one taken at upload; cached rows of
+ * locked and its lock-free path — fingerprints the host range (66 cache lines: first, last and a
+ * golden-ratio sequence of positions between them) and uploads the range again when the fingerprint differs from the one taken at upload; cached rows of
  * the old content are dropped.  A rewrite that happens to leave all sampled lines unchanged (a few groups patched
  * in place) is only caught in strict mode — BGSA_HIP_STRICT_RESIDENT=1 in the environment or
  * bgsa_hip_set_strict_resident(1) — which keeps a host copy of what was uploaded and compares every byte of the

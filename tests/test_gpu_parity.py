@@ -596,7 +596,7 @@ def test_resident_bucket_rewritten_behind_the_librarys_back_is_not_scored_stale(
     leaves every sampled cache line alone — one group patched in place — is the case the documented strict mode is for."""
     L = B.lib()
     nq, length, wn = 6, 150, 5
-    n = 64 * 40
+    n = 64 * 300                       # many more groups than fingerprint samples: some group holds no sampled line
     q = oracle.gen_reads(91, nq, length)
     s_a, _ = B.pad_rows(oracle.gen_reads(92, n, length))
     s_b, _ = B.pad_rows(oracle.gen_reads(93, n, length))
@@ -622,7 +622,7 @@ def test_resident_bucket_rewritten_behind_the_librarys_back_is_not_scored_stale(
         L.hip_cal_align_score(qmapped.ctypes.data, x.ctypes.data, out.ctypes.data, length, nq, length, n, 0, nq, wn, 27, None)
         return out
 
-    def fine(chunk=7):
+    def fine(chunk=41):
         out = np.zeros((nq, n), dtype=np.int16)
         groups = n // 64
         for i in range(nq):
@@ -652,7 +652,10 @@ def test_resident_bucket_rewritten_behind_the_librarys_back_is_not_scored_stale(
         # --- one group patched in place, away from every sampled line: the fingerprint cannot see it (documented), the
         # strict mode does — through both seams
         lines = x.nbytes // 64
-        sampled = {(j * (lines - 1)) // 33 for j in range(34)}
+        sampled, weyl = set(), 0                  # capi.hip: range_fingerprint — first line, last line, a golden-ratio sequence
+        for j in range(min(lines, 66)):
+            weyl = (weyl + 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
+            sampled.add(0 if j == 0 else (lines - 1 if j == 1 else (weyl * lines) >> 64))
         g_lines = gw * 4 // 64
         victim = next(g for g in range(1, n // 64) if not any(g * g_lines <= ln < (g + 1) * g_lines for ln in sampled))
         y[:] = 0
