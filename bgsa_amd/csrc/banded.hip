@@ -559,21 +559,29 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
         if (group0 >= n_groups) return;
     }
     int n_regroup = 0;   // wave-uniform
+    // DYN: what does not depend on the task is invariant in the task loop, and the compiler would keep it — per-lane base
+    // pointers, the lane's byte offsets — in VGPRs across the row loop (89 instead of 73 registers: the sixth wave per SIMD).
+    // Laundered through an empty asm these values are redefined per task as far as the compiler can tell, and recomputed.
+    int word_num_t = word_num;
+    const uint32_t *mext_t = mext;
+    int8_t *out_t = out;
+    unsigned lane_t = static_cast<unsigned>(lane);
+    if constexpr (DYN) asm volatile("" : "+s"(word_num_t), "+s"(mext_t), "+s"(out_t), "+v"(lane_t));
     // an odd group count leaves the last wave's second half without a group: it runs the first one's again (loads only)
     const bool has[2] = {true, G == 2 && group0 + 1 < n_groups};
-    const size_t group_words = static_cast<size_t>(kChars) * word_num * kLanes;
-    const uint32_t *g = mext + static_cast<size_t>(group0) * group_words;
+    const size_t group_words = static_cast<size_t>(kChars) * word_num_t * kLanes;
+    const uint32_t *g = mext_t + static_cast<size_t>(group0) * group_words;
     const uint32_t gstride[2] = {0u, has[1] ? static_cast<uint32_t>(group_words * sizeof(uint32_t)) : 0u};
 
     uint32_t first[G][kChars][2];   // words 0 and 1 stay across the tile's queries; word 2 on is fetched by the row loop
     unsigned long long base[kChars];
 #pragma unroll
     for (int c = 0; c < kChars; c++) {
-        base[c] = uniform_u64(reinterpret_cast<unsigned long long>(g + static_cast<size_t>(c) * word_num * kLanes));
+        base[c] = uniform_u64(reinterpret_cast<unsigned long long>(g + static_cast<size_t>(c) * word_num_t * kLanes));
 #pragma unroll
         for (int gg = 0; gg < G; gg++)
 #pragma unroll
-            for (int w = 0; w < 2; w++) first[gg][c][w] = g[gstride[gg] / 4 + (c * word_num + w) * kLanes + lane];
+            for (int w = 0; w < 2; w++) first[gg][c][w] = g[gstride[gg] / 4 + (c * word_num_t + w) * kLanes + lane_t];
     }
     const int h = k;
     const uint32_t band = static_cast<uint32_t>((1ull << (k + h + 1)) - 1ull);
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
 
     const int q0 = tile * q_tile;
     const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
-    int8_t *dst = out + static_cast<size_t>(group0) * kLanes + lane;
+    int8_t *dst = out_t + static_cast<size_t>(group0) * kLanes;      // wave-uniform: the lane joins at the stores
 
     for (int q = q0; q <= q1; q++) {
         // the dense pass over the listed pairs (see banded_asm_kernel): one pair per lane, from row 0
@@ -591,8 +599,8 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
             if (lane < n_regroup) {
                 const uint32_t entry = regroup[lane];
                 const uint32_t gg = (entry >> 6) & 1u;
-                banded_finish_pair_cut(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num, k, static_cast<int>(cut_rows),
-                                       out + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes, ld);
+                banded_finish_pair_cut(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num_t, k, static_cast<int>(cut_rows),
+                                       out_t + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes, ld);
             }
             __builtin_amdgcn_wave_barrier();
             n_regroup = 0;
@@ -610,7 +618,9 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
                 M[gg][c][0] = first[gg][c][0];   // the window of row 0: the first word itself
                 M[gg][c][1] = first[gg][c][1];   // the word behind it
             }
-            voff[gg] = static_cast<uint32_t>(lane * 4 + 2 * kLanes * 4) + gstride[gg];   // word 2 of this lane
+            unsigned lane_q = static_cast<unsigned>(lane);
+            if constexpr (DYN) asm volatile("" : "+v"(lane_q));
+            voff[gg] = static_cast<uint32_t>(lane_q * 4 + 2 * kLanes * 4) + gstride[gg];   // word 2 of this lane
         }
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
@@ -622,6 +632,8 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
         else
             banded_cut_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         note_stream_fault(fault_word, left);
+        unsigned lane_s = static_cast<unsigned>(lane);          // the lane's offset in the stores below, formed here, not kept
+        if constexpr (DYN) asm volatile("" : "+v"(lane_s));
         if (early) {
             // few lanes within the limit at a late test: they wait in the regroup list, the others are rejected here
 #pragma unroll
@@ -629,7 +641,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
                 if (!has[gg]) continue;
                 const unsigned long long alive = ~dead_mask[gg];
                 if ((dead_mask[gg] >> lane) & 1ull)
-                    dst[static_cast<size_t>(q) * ld + gg * kLanes] = static_cast<int8_t>(HIP_MAX_ERROR);
+                    dst[static_cast<size_t>(q) * ld + gg * kLanes + lane_s] = static_cast<int8_t>(HIP_MAX_ERROR);
                 else
                     regroup[n_regroup + __popcll(alive & ((1ull << lane) - 1ull))] =
                         (static_cast<uint32_t>(q - q0) << 8) | (static_cast<uint32_t>(gg) << 6) | lane;
@@ -653,7 +665,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
                 }
                 if (!dead) result = static_cast<int8_t>(best);
             }
-            dst[static_cast<size_t>(q) * ld + gg * kLanes] = result;
+            dst[static_cast<size_t>(q) * ld + gg * kLanes + lane_s] = result;
         }
     }
     if constexpr (DYN) task = resolve_wave_task(task_issued);
@@ -834,13 +846,16 @@ int banded_impl()
     return impl;
 }
 
-// Dynamic task handout for the one-word-window kernels: BGSA_BANDED_DYNAMIC=1 (measurement knob; the loop's registers cost
-// the two-group kernel its fifth wave per SIMD).
+// Dynamic task handout for the one-word-window kernels.  Until round 4 the task loop cost the two-group kernel a wave per
+// SIMD (89 instead of 73 VGPRs: 290.0 -> 306.6 ms with every pair surviving) and the counter was an off-by-default knob; with the
+// loop's invariants laundered out of the VGPRs (banded_cut_kernel: 75) it is the default: same box, static grid -> counter,
+// 10k x 1M x 150 bp, k = 8: planted mix 85.6 -> 84.8 ms, 1 % of all pairs surviving 106.2 -> 102.1, every pair surviving
+// 276.5 -> 272.9 (scripts/r04_dyn_ab.sh, profiles/r04_dyn_ab.txt).  BGSA_BANDED_DYNAMIC=0 restores the static grid.
 bool banded_dynamic_tasks()
 {
     static const bool on = [] {
         const char *e = getenv("BGSA_BANDED_DYNAMIC");
-        return e && e[0] == '1' && dynamic_tasks();
+        return !(e && e[0] == '0') && dynamic_tasks();
     }();
     return on;
 }

@@ -83,16 +83,28 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
         }
 
         uint32_t P[kChars][NW];
-        const uint32_t *g = peq + static_cast<size_t>(group) * kChars * word_num * kLanes + lane;
+        // In the task loop of the DYN instantiation everything that does not depend on the task is loop-invariant, and the
+        // compiler keeps it in VGPRs across the row loop: five "word exists" flags and the two per-lane base pointers — ten
+        // registers, 103 instead of 93 at five words, the 150 bp kernel's fifth wave per SIMD.  Values laundered through an
+        // empty asm are redefined per task as far as the compiler can tell, so they are recomputed (a handful of scalar
+        // instructions per task) instead of kept.
+        int wn = word_num;
+        const uint32_t *peq_t = peq;
+        int16_t *out_t = out;
+        unsigned lane_t = static_cast<unsigned>(lane);
+        if constexpr (DYN) asm volatile("" : "+s"(wn), "+s"(peq_t), "+s"(out_t), "+v"(lane_t));
+        const uint32_t *g = peq_t + static_cast<size_t>(group) * kChars * wn * kLanes + lane_t;
 #pragma unroll
         for (int c = 0; c < kChars; c++)
 #pragma unroll
             for (int w = 0; w < NW; w++)
-                P[c][w] = (w < word_num) ? g[(c * word_num + w) * kLanes] : 0u;
+                P[c][w] = (w < wn) ? g[(c * wn + w) * kLanes] : 0u;
 
         const int q0 = tile * q_tile;
         const int q1 = (q0 + q_tile < n_queries) ? q0 + q_tile : n_queries;
-        int16_t *dst = out + static_cast<size_t>(group) * kLanes + lane;
+        // (the store address is formed at the store from this wave-uniform base and the lane: a per-lane 64-bit pointer kept
+        // across the row loop is two more registers)
+        int16_t *dst = out_t + static_cast<size_t>(group) * kLanes;
 
         for (int q = q0; q < q1; q++) {
             if constexpr (DYN) {   // the next task, asked for under this one's last query: late enough that the tail of a
@@ -113,7 +125,9 @@ __global__ __launch_bounds__(256) void bitpal_asm_kernel(
             } else {
                 score = kBitpalGap * (ref_len + read_len) + bitpal_column_sum<NW>(st, 0, read_len);
             }
-            dst[static_cast<size_t>(q) * ld] = static_cast<int16_t>(score);
+            unsigned lane_s = static_cast<unsigned>(lane);
+            if constexpr (DYN) asm volatile("" : "+v"(lane_s));      // (the lane's byte offset is formed here, not kept)
+            dst[static_cast<size_t>(q) * ld + lane_s] = static_cast<int16_t>(score);
         }
         if constexpr (DYN) task = resolve_wave_task(task_issued);
     } while (DYN && task < n_tasks);

@@ -1302,7 +1302,7 @@ print("knobs ok")
                                  {"BGSA_DYNAMIC_TASKS": "0"},                                 # static grids at every launch size
                                  {"BGSA_DYNAMIC_MIN_TASKS": "1"},                             # the task counter at every launch size (default: long launches only)
                                  {"BGSA_DYNAMIC_MIN_TASKS": "1", "BGSA_DYNAMIC_TASK_WORDS": "1"},   # ... with one- and two-query tasks
-                                 {"BGSA_DYNAMIC_MIN_TASKS": "1", "BGSA_BANDED_DYNAMIC": "1"},     # ... and the banded kernel on the counter too
+                                 {"BGSA_BANDED_DYNAMIC": "0"},                                # the banded kernel on its static grid (the default until round 4)
                                  {"BGSA_BANDED_PUSH_SOLID": "0", "BGSA_BANDED_SOLID_MARGIN": "0"},   # any lane within the limit counts as a solid survivor, from the first test
                                  {"BGSA_BANDED_PUSH_SOLID": "48", "BGSA_BANDED_GROUPS": "2"},
                                  {"BGSA_BANDED_PUSH_MAX": "0"},                               # no survivor queue
