@@ -528,7 +528,12 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
 // Registers: the loop lives on the waves a SIMD can choose from (4 -> 5 -> 6 waves: +6-11 %, +4-6 %), so the row
 // loop keeps two registers per class and group (gen_rows_asm.py: gen_banded_cut_function) and the dense pass is kept narrow:
 // 73 VGPRs = six waves per SIMD.
-template <int G, bool DYN = false>
+// FORM (round 4): 0 = the one-word windows above (k <= 12); 1 / 2 = the SAME kernel around the funnel-shift rows of thresholds
+// 13 .. 15 (32-bit band) / 16 .. 31 (64-bit pair) — banded_funnel{32,64}_rows_asm_g2: what two groups per wave, the woven dispatch,
+// the solid-survivor rule and the task counter are worth to the rows that have to keep their v_alignbit.  Those
+// forms keep three / four match-string words per class and group (the last one the prefetch target) and use the funnel-shift
+// dense pass (banded_finish_pair<T>).
+template <int G, bool DYN = false, int FORM = 0>
 __global__ __launch_bounds__(256) void banded_cut_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
     long long ld, int n_groups, int word_num, int n_queries, int q_tile, int k, int stream_stride_bytes,
@@ -573,18 +578,27 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
     const uint32_t *g = mext_t + static_cast<size_t>(group0) * group_words;
     const uint32_t gstride[2] = {0u, has[1] ? static_cast<uint32_t>(group_words * sizeof(uint32_t)) : 0u};
 
-    uint32_t first[G][kChars][2];   // words 0 and 1 stay across the tile's queries; word 2 on is fetched by the row loop
+    constexpr int NM = FORM == 0 ? 2 : (FORM == 1 ? 3 : 4);   // resident match-string words per class and group
+    constexpr int NS = FORM == 2 ? 5 : 3;                      // state registers per group
+    // FORM 0: the first two words of every class stay in registers across the tile's queries (20 VGPRs with two groups); the
+    // funnel forms would need 30 / 40 for that and re-read their first words per query instead (L2 hits: the group's block
+    // is 5 x NM x 256 B per query against 150 rows x 24 / 44 vector instructions) — 92 -> 62 and 123 -> 83 VGPRs
+    constexpr int NF = FORM == 0 ? NM : 1;
+    uint32_t first[G][kChars][NF];   // (word NM on is fetched by the row loop)
     unsigned long long base[kChars];
 #pragma unroll
     for (int c = 0; c < kChars; c++) {
         base[c] = uniform_u64(reinterpret_cast<unsigned long long>(g + static_cast<size_t>(c) * word_num_t * kLanes));
+        if constexpr (FORM == 0) {
 #pragma unroll
-        for (int gg = 0; gg < G; gg++)
+            for (int gg = 0; gg < G; gg++)
 #pragma unroll
-            for (int w = 0; w < 2; w++) first[gg][c][w] = g[gstride[gg] / 4 + (c * word_num_t + w) * kLanes + lane_t];
+                for (int w = 0; w < NM; w++) first[gg][c][w] = g[gstride[gg] / 4 + (c * word_num_t + w) * kLanes + lane_t];
+        }
     }
     const int h = k;
-    const uint32_t band = static_cast<uint32_t>((1ull << (k + h + 1)) - 1ull);
+    const unsigned long long band64 = (k + h + 1 >= 64) ? ~0ull : ((1ull << (k + h + 1)) - 1ull);
+    const uint32_t band = static_cast<uint32_t>(band64);
     const uint32_t limit = static_cast<uint32_t>(h + 1);   // err > k+h+1  <=>  errors since row k > h+1
 
     const int q0 = tile * q_tile;
@@ -599,35 +613,53 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
             if (lane < n_regroup) {
                 const uint32_t entry = regroup[lane];
                 const uint32_t gg = (entry >> 6) & 1u;
-                banded_finish_pair_cut(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num_t, k, static_cast<int>(cut_rows),
-                                       out_t + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes, ld);
+                int8_t *tile_out = out_t + static_cast<size_t>(q0) * ld + static_cast<size_t>(group0 + gg) * kLanes;
+                if constexpr (FORM == 0)
+                    banded_finish_pair_cut(entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num_t, k, static_cast<int>(cut_rows),
+                                           tile_out, ld);
+                else
+                    banded_finish_pair<typename std::conditional<FORM == 2, uint64_t, uint32_t>::type>(
+                        entry & ~0x40u, g + gg * group_words, content, ref_start + q0, len, word_num_t, k, tile_out, ld);
             }
             __builtin_amdgcn_wave_barrier();
             n_regroup = 0;
         }
         if (q == q1) break;
-        uint32_t st[3 * G];
+        uint32_t st[NS * G];
 #pragma unroll
-        for (int i = 0; i < 3 * G; i++) st[i] = 0u;
-        uint32_t M[G][kChars][2];
+        for (int i = 0; i < NS * G; i++) st[i] = 0u;
+        uint32_t M[G][kChars][NM];
         uint32_t voff[G];
 #pragma unroll
         for (int gg = 0; gg < G; gg++) {
 #pragma unroll
-            for (int c = 0; c < kChars; c++) {
-                M[gg][c][0] = first[gg][c][0];   // the window of row 0: the first word itself
-                M[gg][c][1] = first[gg][c][1];   // the word behind it
-            }
+            for (int c = 0; c < kChars; c++)
+#pragma unroll
+                for (int w = 0; w < NM; w++) {
+                    if constexpr (FORM == 0) {
+                        M[gg][c][w] = first[gg][c][w];   // the window of row 0 = the first word itself, and the word behind it
+                    } else {
+                        unsigned lane_m = static_cast<unsigned>(lane);
+                        asm volatile("" : "+v"(lane_m));      // per query: the loads are not to be hoisted out of the query loop and kept
+                        M[gg][c][w] = g[gstride[gg] / 4 + (c * word_num_t + w) * kLanes + lane_m];
+                    }
+                }
             unsigned lane_q = static_cast<unsigned>(lane);
             if constexpr (DYN) asm volatile("" : "+v"(lane_q));
-            voff[gg] = static_cast<uint32_t>(lane_q * 4 + 2 * kLanes * 4) + gstride[gg];   // word 2 of this lane
+            voff[gg] = static_cast<uint32_t>(lane_q * 4 + NM * kLanes * 4) + gstride[gg];   // word NM of this lane
         }
         const unsigned long long s =
             reinterpret_cast<unsigned long long>(streams) + static_cast<unsigned long long>(q) * stream_stride_bytes;
         const int n_windows = __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2);
         unsigned long long dead_mask[G];
         int left, early;
-        if constexpr (G == 2)
+        if constexpr (FORM == 2 && G == 1)
+            banded_funnel64_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, static_cast<uint32_t>(band64 >> 32), cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
+        else if constexpr (FORM == 2)
+            banded_funnel64_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, static_cast<uint32_t>(band64 >> 32), cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
+        else if constexpr (FORM == 1)
+            banded_funnel32_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
+        else if constexpr (G == 2)
             banded_cut_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         else
             banded_cut_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
@@ -656,11 +688,15 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
             int8_t result = static_cast<int8_t>(HIP_MAX_ERROR);
             if (dead_mask[gg] != ~0ull) {
                 // :230-245 — walk the last row across the band, keep the minimum.
-                const uint32_t vp = st[3 * gg], vn = st[3 * gg + 1];
-                uint32_t err = static_cast<uint32_t>(k) + st[3 * gg + 2], best = err;
+                unsigned long long vp = st[NS * gg], vn = st[NS * gg + (FORM == 2 ? 2 : 1)];
+                if constexpr (FORM == 2) {
+                    vp |= static_cast<unsigned long long>(st[NS * gg + 1]) << 32;
+                    vn |= static_cast<unsigned long long>(st[NS * gg + 3]) << 32;
+                }
+                uint32_t err = static_cast<uint32_t>(k) + st[NS * gg + NS - 1], best = err;
                 for (int i = 0; i <= h; i++) {
-                    err += (vp >> i) & 1u;
-                    err -= (vn >> i) & 1u;
+                    err += static_cast<uint32_t>((vp >> i) & 1ull);
+                    err -= static_cast<uint32_t>((vn >> i) & 1ull);
                     best = err < best ? err : best;
                 }
                 if (!dead) result = static_cast<int8_t>(best);
@@ -904,7 +940,20 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     const int phase = banded_stream_phase(k), cut = banded_stream_cut(k);
-    const int G = cut > 0 ? banded_groups() : 1;
+    // the two-group loop around the funnel-shift rows (k >= 13): the default since round 4; BGSA_BANDED_IMPL=a keeps round 2's
+    // one-group loops (banded_asm_kernel) at every k, BGSA_BANDED_GROUPS=1 at k >= 13
+    // measured (scripts/r04_banded_funnel_ab.sh, r04_banded_pair_loop.sh; every pair surviving): the 32-bit rows gain 8 % from the
+    // two-group loop (random pairs 14-24 %); the 64-bit pair LOSES 4.5 % with two groups, loses 1.4 % with one group on a static
+    // grid and gains 2.2 % with one group on the task counter (k = 31: 660.8 -> 646.4 ms): that is its default.
+    // BGSA_BANDED_PAIR_LOOP=0: round 2's loop; =2: two groups (A/B flavour of the library only)
+    static const int pair_loop = [] { const char *e = getenv("BGSA_BANDED_PAIR_LOOP"); return e ? atoi(e) : 1; }();
+    int form = -1, G = 1;
+    if (cut > 0) { form = 0; G = banded_groups(); }
+    else if (phase == 0 && banded_impl() == 0 && banded_groups() == 2 && k <= 15) { form = 1; G = 2; }
+    else if (phase == 0 && banded_impl() == 0 && k > 15 && (pair_loop == 1 || pair_loop == 2)) { form = 2; G = pair_loop; }
+#if !BGSA_AB_KERNELS
+    if (form == 2 && G == 2) return ab_knob_refused("BGSA_BANDED_PAIR_LOOP=2");
+#endif
     const int64_t n_waves = (n_groups + G - 1) / G;
     const int q_tile = pick_query_tile(nq, n_waves, static_cast<long long>(len) * G, 32);
     if (int rc = launch_pack_banded(d_content, len, k, phase, cut, ref_start, ref_end, d_workspace, stream)) return rc;
@@ -928,16 +977,30 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int8_t *d_results, 
     // mix and 88 ms on random pairs; with margin 2 random stragglers pass for survivors: 107 ms from row k + 32)
     const int margin = banded_push_solid_margin() >= 0 ? banded_push_solid_margin() : (k + 2) / 2;
     const uint32_t solid_limit = static_cast<uint32_t>(k + 1 > margin ? k + 1 - margin : 0);
-    if (cut > 0) {
+    if (cut > 0 || form > 0) {
         unsigned *counter = nullptr;
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
         if (banded_dynamic_tasks() && dynamic_tasks_fit(blocks * kWavesPerBlock)) {
             counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
             BGSA_HIP_TRY(hipMemsetAsync(counter, 0, 8, stream));
-            const int resident = G == 2 ? persistent_blocks_for(banded_cut_kernel<2, true>) : persistent_blocks_for(banded_cut_kernel<1, true>);
+#if BGSA_AB_KERNELS
+            const int resident = (form == 2 && G == 2) ? persistent_blocks_for(banded_cut_kernel<2, true, 2>)
+                               : form == 2 ? persistent_blocks_for(banded_cut_kernel<1, true, 2>)
+#else
+            const int resident = form == 2 ? persistent_blocks_for(banded_cut_kernel<1, true, 2>)
+#endif
+                               : form == 1 ? persistent_blocks_for(banded_cut_kernel<2, true, 1>)
+                               : G == 2 ? persistent_blocks_for(banded_cut_kernel<2, true>) : persistent_blocks_for(banded_cut_kernel<1, true>);
             grid = dim3(static_cast<unsigned>(blocks < resident ? blocks : resident), 1u);
         }
-        auto kernel = G == 2 ? (counter ? banded_cut_kernel<2, true> : banded_cut_kernel<2, false>)
+#if BGSA_AB_KERNELS
+        auto kernel = (form == 2 && G == 2) ? (counter ? banded_cut_kernel<2, true, 2> : banded_cut_kernel<2, false, 2>)
+                    : form == 2 ? (counter ? banded_cut_kernel<1, true, 2> : banded_cut_kernel<1, false, 2>)
+#else
+        auto kernel = form == 2 ? (counter ? banded_cut_kernel<1, true, 2> : banded_cut_kernel<1, false, 2>)
+#endif
+                    : form == 1 ? (counter ? banded_cut_kernel<2, true, 1> : banded_cut_kernel<2, false, 1>)
+                    : G == 2 ? (counter ? banded_cut_kernel<2, true> : banded_cut_kernel<2, false>)
                              : (counter ? banded_cut_kernel<1, true> : banded_cut_kernel<1, false>);
         static const unsigned lds_pad = [] { const char *e = getenv("BGSA_BANDED_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds_pad, stream,
@@ -1011,6 +1074,12 @@ const char *banded_kernel_name(int word_num)
     if (banded_impl() == 2 && g_last_k <= 15) return "banded_chunk_kernel";
     if (banded_stream_phase(g_last_k) > 0) return "banded_asm_kernel<false, true>";
     if (banded_stream_cut(g_last_k) > 0) return banded_groups() == 2 ? "banded_cut_kernel<2>" : "banded_cut_kernel<1>";
+    if (banded_impl() == 0 && banded_groups() == 2 && g_last_k <= 15) return "banded_cut_kernel<2, funnel32>";
+    if (banded_impl() == 0 && g_last_k > 15) {
+        static const int pair_loop = [] { const char *e = getenv("BGSA_BANDED_PAIR_LOOP"); return e ? atoi(e) : 1; }();
+        if (pair_loop == 1) return "banded_cut_kernel<1, funnel64>";
+        if (pair_loop == 2) return "banded_cut_kernel<2, funnel64>";
+    }
     return g_last_k <= 15 ? "banded_asm_kernel<false, false>" : "banded_asm_kernel<true, false>";
 }
 

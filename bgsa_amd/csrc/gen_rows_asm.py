@@ -553,9 +553,13 @@ def gen_banded_function(wide: bool, phase: bool = False) -> str:
 """
 
 
-def gen_banded_cut_function(groups: int) -> str:
-    """Row loop of the one-word-window banded kernel (k <= 12; rows_ir.banded_cut_body), for one or two subject
-    groups per wave.  Same threaded-code skeleton, stream and events as gen_banded_function, plus EVENT bit 5 = cut.
+def gen_banded_cut_function(groups: int, form: str = "cut") -> str:
+    """form = "cut": row loop of the one-word-window banded kernel (k <= 12; rows_ir.banded_cut_body), for one or two subject
+    groups per wave.  form = "funnel32" / "funnel64" (round 4): the same loop — two groups per wave sharing every dispatch,
+    shift counter and event, the next token's dispatch woven under the last row, solid-survivor pushes — around the
+    funnel-shift rows of thresholds 13 .. 15 (rows_ir.banded_funnel_body: one v_alignbit per group in the row, three
+    match-string words per class and group, the last one the prefetch target) and 16 .. 31 (the 64-bit pair: four words);
+    no cut events.  Same threaded-code skeleton, stream and events as gen_banded_function, plus EVENT bit 5 = cut.
     Per group and class TWO registers: m0 = the window the rows shift (A: at an advance the 32-bit match-string word the
     next 32 rows start in), m1 = the word behind it (B).  advance (bit 1, every 32 rows): A <- B, fetch B (awaited by
     the next cut, 16 or 8 rows later); cut (bit 5, every `cutrows` rows in between): A <- {B >> rows cut so far, A} >>
@@ -565,9 +569,14 @@ def gen_banded_cut_function(groups: int) -> str:
     With two groups the tests, the push decision and the early exit look at both: the wave stops when all 128 lanes
     are past the limit."""
     G = groups
-    body = R.banded_cut_body(G)
-    n_state = 3 * G
-    acc = [3 * g + 2 for g in range(G)]
+    assert form in ("cut", "funnel32", "funnel64")
+    funnel, wide = form != "cut", form == "funnel64"
+    body = R.banded_cut_body(G) if not funnel else R.schedule(R.banded_funnel_body(G, wide), 8)
+    per_state = 5 if wide else 3
+    n_state = per_state * G
+    acc = [per_state * g + per_state - 1 for g in range(G)]
+    n_m = 2 if not funnel else (4 if wide else 3)      # match-string words per class and group (funnel: the last = prefetch target)
+    n_eq = 3 if wide else 2                            # ... that the row reads
     slot_of, n_slots = body.allocate_temps()
     S_CUT, S_SH, S_ARG, S_CUTROWS, S_THR, S_CNT = "s72", "s73", "s74", "s75", "s78", "s79"
     S_DEAD = ["s[76:77]", "s[96:97]"]
@@ -582,10 +591,15 @@ def gen_banded_cut_function(groups: int) -> str:
         def reg(name: str) -> str:
             if name.startswith("S"):
                 return f"%[s{name[1:]}]"
+            if name.startswith("E") and funnel:
+                j = int(name[1:])
+                return f"%[m{j % n_eq}_{c}_{j // n_eq}]"
             if name.startswith("E"):
                 return f"%[m0_{c}_{name[1:]}]"       # the window: register A
-            if name == "$mask":
+            if name in ("$mask", "$mask_lo"):
                 return "%[vmask]"
+            if name == "$mask_hi":
+                return "%[vmask_hi]"
             if name == "$sh":
                 return S_SH
             if name == "$one":
@@ -698,7 +712,9 @@ def gen_banded_cut_function(groups: int) -> str:
         rows = body.emit_asm(reg_for(c), c)
         if os.environ.get("BGSA_GEN_BANDED_WEAVE", "1") == "0":   # A/B builds: the dispatch behind the row
             return rows + [f"s_add_u32 {S_SH}, {S_SH}, 1"] + disp()
-        head, rest = rows[:G], rows[G:]                      # the G window shifts read S_SH
+        n_head = G * (2 if wide else 1)                      # the window shifts read S_SH (the scheduler keeps them in front)
+        assert all(S_SH in ln for ln in rows[:n_head]) and not any(S_SH in ln for ln in rows[n_head:])
+        head, rest = rows[:n_head], rows[n_head:]
         out = head + [f"s_add_u32 {S_SH}, {S_SH}, 1"]
         d = disp()
         scalars, jump = d[:-1], d[-1]
@@ -782,10 +798,11 @@ def gen_banded_cut_function(groups: int) -> str:
         "s_waitcnt vmcnt(0)",
     ]
     for g in range(G):       # (vmcnt(0): a word fetched by the previous advance that no cut has waited for yet)
-        asm += [f"v_mov_b32 %[m0_{c}_{g}], %[m1_{c}_{g}]" for c in range(5)]
+        for w in range(n_m - 1):
+            asm += [f"v_mov_b32 %[m{w}_{c}_{g}], %[m{w + 1}_{c}_{g}]" for c in range(5)]
     for g in range(G):
         for c in range(5):
-            asm.append(f"global_load_dword %[m1_{c}_{g}], %[voff{g}], {S_BASE[c]}")
+            asm.append(f"global_load_dword %[m{n_m - 1}_{c}_{g}], %[voff{g}], {S_BASE[c]}")
     asm += [f"v_add_u32 %[voff{g}], 0x100, %[voff{g}]" for g in range(G)]
     asm += [
         f"s_mov_b32 {S_SH}, 0",
@@ -814,15 +831,40 @@ def gen_banded_cut_function(groups: int) -> str:
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
-    outs += [f'[m{w}_{c}_{g}] "+v"(M[{g}][{c}][{w}])' for g in range(G) for c in range(5) for w in range(2)]
+    outs += [f'[m{w}_{c}_{g}] "+v"(M[{g}][{c}][{w}])' for g in range(G) for c in range(5) for w in range(n_m)]
     outs += [f'[voff{g}] "+v"(voff[{g}])' for g in range(G)]
     outs += [f'[dead{g}] "=s"(dead[{g}])' for g in range(G)]
     outs += ['[left] "=s"(left)', '[early] "=s"(early)']
     outs += [f'[t{i}] "=&v"(tmp[{i}])' for i in range(n_slots)]
-    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[vmask] "v"(band_mask)', '[thr] "s"(limit)', '[cutrows] "s"(cut_rows)',
+    ins = ['[qp] "s"(stream)', '[nwin] "s"(n_windows)', '[vmask] "v"(band_mask)'] + (['[vmask_hi] "v"(band_mask_hi)'] if wide else []) + \
+          ['[thr] "s"(limit)', '[cutrows] "s"(cut_rows)',
            '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)', '[pushsolid] "s"(push_row_solid)', '[solidthr] "s"(solid_limit)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
     clob = ", ".join(f'"{x}"' for x in clobbers)
+    if funnel:
+        bits = 64 if wide else 32
+        return f"""
+// Funnel-shift banded rows ({bits}-bit band: thresholds {'16 .. 31' if wide else '13 .. 15'}), {G} subject group{'s' if G > 1 else ''} per wave: {body.valu_count()} VALU per row
+// ({sum(op.kind in ('alignbit',) for op in body.ops)} funnel shifts among them), {n_slots} temporaries.  state[{per_state}g ..] = {{VP, VN, errors since row k}} of group g
+// (VP lo / hi, VN lo / hi, errors when the band is a pair); M[g][c] = {n_m} consecutive 32-bit words of class c's offset match string, the last
+// one the prefetch target; voff[g] = byte offset of the next word to fetch relative to base[c] (group 1: the group stride included);
+// dead / left / early and the push rules as banded_cut_rows_asm_g{G} (cut_rows is not used: the stream carries no cut events).
+__device__ __forceinline__ void banded_funnel{bits}_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][{n_m}], uint32_t (&voff)[{G}],
+                                                       const unsigned long long (&base)[5],
+                                                       const unsigned long long stream, const int n_windows,
+                                                       const uint32_t band_mask, {'const uint32_t band_mask_hi, ' if wide else ''}const uint32_t cut_rows,
+                                                       const uint32_t limit, const uint32_t push_row, const uint32_t push_row_solid, const uint32_t solid_limit,
+                                                       const uint32_t push_max, unsigned long long (&dead)[{G}],
+                                                       int &left, int &early)
+{{
+    uint32_t tmp[{max(n_slots, 1)}];
+    asm volatile(
+{text}
+        : {", ".join(outs)}
+        : {", ".join(ins)}
+        : {clob});
+}}
+"""
     return f"""
 // One-word-window banded rows, {G} subject group{'s' if G > 1 else ''} per wave: {body.valu_count()} VALU per row, all fast class
 // ({sum(op.kind in ('alignbit',) for op in body.ops)} funnel shifts in the row; the cut event holds them), {n_slots} temporaries.
@@ -1467,7 +1509,9 @@ def main() -> int:
     (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))
     # ---- banded -------------------------------------------------------------------------------
     (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(False, phase=True) + gen_banded_function(True) +
-                                              gen_banded_chunk_function() + gen_banded_cut_function(1) + gen_banded_cut_function(2))
+                                              gen_banded_chunk_function() + gen_banded_cut_function(1) + gen_banded_cut_function(2) +
+                                              gen_banded_cut_function(2, "funnel32") + gen_banded_cut_function(2, "funnel64") +
+                                              gen_banded_cut_function(1, "funnel64"))
     return 0
 
 

@@ -716,6 +716,42 @@ def banded_body() -> Body:
     return b
 
 
+def banded_funnel_body(groups: int = 1, wide: bool = False) -> Body:
+    """The funnel-shift rows (banded_body: k <= 15, banded_body64: k <= 31) for one or two subject groups per wave that share
+    the stream and its scalar work, interleaved instruction by instruction as banded_cut_body's: group g's state is
+    S<n*g .. n*g + n - 1> (n = 3: VP, VN, errors; wide n = 5: VP lo/hi, VN lo/hi, errors), its match-string words
+    E<m*g .. m*g + m - 1> (m = 2, wide 3).  groups = 1 is banded_body() / banded_body64() itself."""
+    base = banded_body64() if wide else banded_body()
+    n_state, n_eq = (5, 3) if wide else (3, 2)
+    per = []
+    for g in range(groups):
+        ops = []
+        for op in base.ops:
+            def rename(r, g=g):
+                if r.startswith("S"):
+                    return f"S{n_state * g + int(r[1:])}"
+                if r.startswith("E"):
+                    return f"E{n_eq * g + int(r[1:])}"
+                if r.startswith("$"):
+                    return r
+                return f"{r}_{g}"
+            ops.append(Op(op.kind, rename(op.dst) if op.dst else "", tuple(rename(x) for x in op.srcs), op.imm))
+        # units of the interleave: single instructions, and a carry chain (add_co followed by its addc links) as ONE
+        # unit — two groups' chains must not interleave, VCC is one register
+        units = []
+        for op in ops:
+            if op.kind == "addc":
+                units[-1].append(op)
+            else:
+                units.append([op])
+        per.append(units)
+    out = Body()
+    for units in zip(*per):
+        for u in units:
+            out.ops.extend(u)
+    return out
+
+
 def banded_cut_rows(k: int) -> int:
     """Rows between two cuts of the one-word window form (bgsa_common.h: banded_cut_rows): the band's 2k + 1 bits,
     offset by up to rows - 1 bits, must fit one 32-bit word.  0: no room worth it (k > 12) — the funnel-shift row."""

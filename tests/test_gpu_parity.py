@@ -68,7 +68,8 @@ def test_bitpal_lengths_vs_oracle(oracle, slen):
 
 
 @pytest.mark.parametrize("length,k", [(150, 8), (150, 4), (150, 15), (150, 16), (150, 31), (64, 8), (65, 8), (73, 8),
-                                      (100, 12), (128, 8), (136, 8), (200, 8), (250, 20), (500, 8), (1000, 8), (2000, 8), (1500, 25)])
+                                      (100, 12), (128, 8), (136, 8), (200, 8), (250, 20), (500, 8), (1000, 8), (2000, 8), (1500, 25),
+                                      (150, 13), (150, 14), (97, 13), (700, 15), (250, 24), (320, 31)])
 def test_banded_vs_oracle(oracle, length, k):
     # includes lengths (65, 136, 200) where the reference itself writes out of bounds: the oracle
     # (and the kernel) follow the in-bounds semantics there (DESIGN.md "banded domain")
@@ -81,7 +82,7 @@ def test_banded_vs_oracle(oracle, length, k):
     assert (want != 127).any() and (want == 127).any()
 
 
-@pytest.mark.parametrize("k,length", [(8, 150), (20, 150), (8, 500), (12, 97)])
+@pytest.mark.parametrize("k,length", [(8, 150), (20, 150), (8, 500), (12, 97), (14, 150), (13, 320), (31, 250)])
 def test_banded_sparse_survivors_take_the_queue(oracle, k, length):
     """One or two near-duplicates per wave of 64 subjects among random reads: the first pass stops those waves
     at a late test and the survivor queue's second pass scores the pairs (banded.hip).  Dense survivors
@@ -1267,7 +1268,7 @@ for length, k in ((64, 8), (97, 12), (128, 4), (160, 15), (500, 8), (33, 3), (15
     sc[:64] = O.mutate(qc[np.arange(64) % 40], np.arange(64) % (2 * k + 6), 912)
     sc[64 * 3 + 5] = O.mutate(qc[7:8], [2], 913)[0]; sc[64 * 4 + 60] = O.mutate(qc[9:10], [k], 914)[0]   # lone survivors: regroup pass
     assert np.array_equal(B.align_all_pairs(qc, sc, algo=B.ALGO_BANDED, k=k), O.banded64(qc, sc, k)), ("banded", length, k)
-for length, k, groups in ((150, 8, 5), (70, 12, 1), (200, 4, 7)):   # an odd number of subject groups: the last wave of the two-groups-per-wave kernel holds one
+for length, k, groups in ((150, 8, 5), (70, 12, 1), (200, 4, 7), (150, 14, 3), (200, 13, 1), (250, 24, 3)):   # an odd number of subject groups: the last wave of the two-groups-per-wave kernels holds one
     qc = O.gen_reads(920 + length, 37, length); sc = O.gen_reads(921 + length, 64 * groups, length)
     sc[:48] = O.mutate(qc[np.arange(48) % 37], np.arange(48) % (2 * k + 6), 922)
     sc[-3] = O.mutate(qc[5:6], [1], 923)[0]                             # a lone survivor in the last group: regroup pass there too
@@ -1303,6 +1304,8 @@ print("knobs ok")
                                  {"BGSA_DYNAMIC_MIN_TASKS": "1"},                             # the task counter at every launch size (default: long launches only)
                                  {"BGSA_DYNAMIC_MIN_TASKS": "1", "BGSA_DYNAMIC_TASK_WORDS": "1"},   # ... with one- and two-query tasks
                                  {"BGSA_BANDED_DYNAMIC": "0"},                                # the banded kernel on its static grid (the default until round 4)
+                                 {"BGSA_BANDED_PAIR_LOOP": "0"},                              # k >= 16: round 2's row loop
+                                 {"BGSA_BANDED_PAIR_LOOP": "2", "BGSA_DYNAMIC_MIN_TASKS": "1"},   # ... two groups per wave (measured slower: A/B flavour), on the counter
                                  {"BGSA_BANDED_PUSH_SOLID": "0", "BGSA_BANDED_SOLID_MARGIN": "0"},   # any lane within the limit counts as a solid survivor, from the first test
                                  {"BGSA_BANDED_PUSH_SOLID": "48", "BGSA_BANDED_GROUPS": "2"},
                                  {"BGSA_BANDED_PUSH_MAX": "0"},                               # no survivor queue
@@ -1329,7 +1332,7 @@ def test_measurement_knobs_do_not_change_results(env):
 def _needs_ab_flavour(env):
     return (any(env.get(k, "")[:1] == "c" for k in ("BGSA_MYERS_IMPL", "BGSA_BITPAL_IMPL", "BGSA_BANDED_IMPL"))
             or env.get("BGSA_BANDED_IMPL", "")[:1] in ("s", "p") or "BGSA_MYERS_PEQ_MAX_WORDS" in env
-            or env.get("BGSA_MYERS_BLOCK_FORM") == "planes")
+            or env.get("BGSA_MYERS_BLOCK_FORM") == "planes" or env.get("BGSA_BANDED_PAIR_LOOP") == "2")
 
 
 @pytest.mark.parametrize("env,algo,length,k", [({"BGSA_MYERS_IMPL": "c"}, 0, 150, 0), ({"BGSA_BANDED_IMPL": "s"}, 1, 150, 8),

@@ -459,3 +459,27 @@ def test_bitpal_generator_domain_is_stated_and_diagnosed(tmp_path):
     assert p.returncode == 1 and "match - mismatch = 150" in p.stderr and "Traceback" not in p.stderr
     p = subprocess.run([sys.executable, str(gen), "--out", str(tmp_path), "2,3,-5"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 1 and "match > mismatch" in p.stderr and "Traceback" not in p.stderr
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_banded_funnel_rows_for_two_groups_equal_two_single_rows(wide):
+    """The two-group funnel-shift rows of thresholds 13 .. 31 (round 4: banded_cut_kernel<2, ., funnel32 / funnel64>): the
+    instruction list that ships — two groups' rows interleaved, carry chains kept whole, list-scheduled — must do to each group
+    exactly what the one-group row (banded_body / banded_body64, CPU-pinned against the oracle above) does, and needs no s_nop."""
+    rng = np.random.default_rng(17 + wide)
+    n_state, n_eq = (5, 3) if wide else (3, 2)
+    one = R.banded_body64() if wide else R.banded_body()
+    two = R.schedule(R.banded_funnel_body(2, wide), 8)
+    assert two.valu_count() == 2 * one.valu_count() and R.count_hazard_nops(two) == 0
+    kinds = [op.kind for op in two.ops]
+    assert kinds[: 2 * (2 if wide else 1)] == ["alignbit"] * (2 * (2 if wide else 1))      # the window shifts lead (they read the shift counter)
+    for trial in range(20):
+        st = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(2 * n_state)]
+        eq = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(2 * n_eq)]
+        sc = {"$sh": int(rng.integers(0, 32)), "$mask": 0x7FFFFFFF, "$mask_lo": 0xFFFFFFFF, "$mask_hi": int(rng.integers(1, 2**31)), "$one": 1}
+        got = [x.copy() for x in st]
+        two.simulate(got, eq, scalars=sc)
+        for g in range(2):
+            want = [x.copy() for x in st[g * n_state:(g + 1) * n_state]]
+            one.simulate(want, eq[g * n_eq:(g + 1) * n_eq], scalars=sc)
+            assert all(np.array_equal(a, b) for a, b in zip(want, got[g * n_state:(g + 1) * n_state])), (wide, trial, g)
