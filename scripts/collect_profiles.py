@@ -19,6 +19,11 @@ dst = Path(__file__).resolve().parent.parent / "profiles"
 dst.mkdir(exist_ok=True)
 HELPERS = ("pack", "preprocess", "map_queries", "scale_scores", "corrupt_stream")
 
+extra = src / "bench_cfg3_k31.json"
+if extra.exists() and extra.stat().st_size:
+    line = [x for x in extra.read_text().strip().splitlines() if x.startswith("{")][-1]
+    json.loads(line)
+    (dst / f"{prefix}_cfg3_k31_bench.json").write_text(line + "\n")
 for c in (2, 3, 4, 5):
     b = src / f"bench_cfg{c}.json"
     if b.exists() and b.stat().st_size:
@@ -32,7 +37,7 @@ for c in (2, 3, 4, 5):
 # PMC: value per launch of the scoring kernel, one file per config (and banded mix)
 groups = {}
 for d in sorted(glob.glob(str(src / "pmc_cfg*"))):
-    m = re.match(r"pmc_(cfg\d(?:_(?:planted|random|dense1pct|survivors))?)_(\w+)$", Path(d).name)
+    m = re.match(r"pmc_(cfg\d(?:_(?:planted|random|dense1pct|survivors|k\d+))?)_(FETCH_SIZE|WRITE_SIZE|SQ)$", Path(d).name)
     if m and Path(d).is_dir():
         groups.setdefault(m.group(1), []).append(d)
 for key, dirs in groups.items():

@@ -2,7 +2,7 @@
 # GPU record for profiles/: the GPU tests, the four BASELINE configs with CPU baselines, rocprofv3 kernel
 # stats and PMC passes per config (separate --pmc runs, as MI355X_MICROARCH.md §HBM prescribes).
 # Run on the GPU box from the repo root:  bash scripts/gpu_round_report.sh <tag> [parts]
-#   parts: any of  tests bench prof pmc banded ubench  (default: all);  CONFIGS="4" limits bench/prof/pmc to config 4
+#   parts: any of  tests bench prof pmc banded k31 ubench  (default: all);  CONFIGS="4" limits bench/prof/pmc to config 4
 tag=${1:-r04}
 parts=${2:-"tests bench prof pmc banded"}
 CONFIGS=${CONFIGS:-"2 3 4 5"}      # restrict the bench / prof / pmc parts to some configs
@@ -49,6 +49,13 @@ if has banded; then
       ctrs=$grp; [ $grp = SQ ] && ctrs=$SQ
       step "pmc cfg3 $mix $grp" 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc_cfg3_${mix}_$grp -- python3 bench.py --config 3 --banded-mix $mix --banded-variants '' --steps 1 --warmup 1 --no-cpu-baseline --no-total --no-clock-probe > $out/pmc_cfg3_${mix}_$grp.log 2>&1
     done
+  done
+fi
+if has k31; then   # the reference's DEFAULT banded threshold (banded/BGSA_CPU/main.c:43), every pair surviving: time + the three PMC passes
+  step "bench cfg3 k31" 300 python bench.py --config 3 --k 31 --banded-mix survivors --banded-variants '' --steps 3 --no-cpu-baseline --no-total > $out/bench_cfg3_k31.json 2> $out/bench_cfg3_k31.err
+  for grp in FETCH_SIZE WRITE_SIZE SQ; do
+    ctrs=$grp; [ $grp = SQ ] && ctrs=$SQ
+    step "pmc cfg3 k31 $grp" 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc_cfg3_k31_$grp -- python3 bench.py --config 3 --k 31 --banded-mix survivors --banded-variants '' --steps 1 --warmup 1 --no-cpu-baseline --no-total --no-clock-probe > $out/pmc_cfg3_k31_$grp.log 2>&1
   done
 fi
 if has ubench; then
