@@ -877,6 +877,11 @@ def main() -> int:
     if dist is not None and world > 1 and args.config == 2 and not args.no_strong and args.length is None:
         wd.stage = "strong leg (config 5 sharded)"
         strong, err = None, None
+        strong_limit = float(os.environ.get("BGSA_BENCH_STRONG_TIMEOUT", "300"))
+        # as for the gather leg: a rank that fails here while its peers wait in a collective shows as a hang, and the
+        # measured line must still go out (marked), with every rank leaving non-zero
+        strong_timer = wd.leg(strong_limit, f"strong leg did not finish within {strong_limit:.0f} s",
+                              lambda line: line.__setitem__("strong", {"error": f"did not finish within {strong_limit:.0f} s"}))
         try:
             del out
             torch.cuda.empty_cache()
@@ -920,6 +925,7 @@ def main() -> int:
             torch.cuda.empty_cache()
         except Exception as e:      # an optional leg never takes the measured line with it
             err = repr(e)
+        strong_timer.cancel()
         if rank == 0:
             with print_lock:
                 result["strong"] = strong if strong is not None else {"error": err}
