@@ -628,6 +628,15 @@ static int pair_groups()
     return g;
 }
 
+// Measurement knob: bytes of unused dynamic LDS per workgroup of the counter kernels — caps the waves per SIMD (160 KB of LDS
+// per CU: 40960 -> four workgroups = four waves per SIMD).  Round 4 asked whether the 150 bp kernel, which issues at 98 % of
+// the sustained clock with eight waves per SIMD, holds a higher clock with fewer (LABNOTES 9.5).
+static unsigned myers_lds_pad()
+{
+    static const unsigned v = [] { const char *e = getenv("BGSA_MYERS_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+    return v;
+}
+
 template <int NW, int G>
 int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
@@ -651,7 +660,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
         counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
         int resident = persistent_blocks();
-        if constexpr (NW <= 8) resident = persistent_blocks_for(myers_global_asm_kernel<NW, G, true>);
+        if constexpr (NW <= 8) resident = persistent_blocks_for(myers_global_asm_kernel<NW, G, true>, myers_lds_pad());
         grid = dim3(static_cast<unsigned>(blocks < resident ? blocks : resident), 1u);
     }
     if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)
@@ -661,7 +670,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     if (int rc = stream_guard(d_workspace, stride, kPairs ? kPairRefill : kCodeRefill, kPairs ? -1 : 7, stream, &fault)) return rc;
     if constexpr (NW <= 8) {   // the widths with registers to spare have a dynamic instantiation
         if (counter) {
-            hipLaunchKernelGGL((myers_global_asm_kernel<NW, G, true>), grid, dim3(256), 0, stream,
+            hipLaunchKernelGGL((myers_global_asm_kernel<NW, G, true>), grid, dim3(256), myers_lds_pad(), stream,
                                static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
                                read_len, static_cast<long long>(read_count), static_cast<int>(n_groups), word_num,
                                nq, q_tile, stride, fault, counter);
