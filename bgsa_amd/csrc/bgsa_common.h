@@ -358,11 +358,14 @@ template <typename Kernel>
 inline int persistent_blocks_for(Kernel kernel, size_t dynamic_lds = 0)
 {
     struct Entry { int dev; const void *fn; size_t lds; int blocks; };
-    static thread_local Entry last{-1, nullptr, 0, 0};
+    static thread_local Entry seen[16] = {};      // a thread alternating between a few kernels asks the runtime once per kernel
+    static thread_local unsigned next = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return persistent_blocks();
     const void *fn = reinterpret_cast<const void *>(kernel);
-    if (last.dev == dev && last.fn == fn && last.lds == dynamic_lds) return last.blocks;
+    for (const Entry &e : seen)
+        if (e.fn == fn && e.dev == dev && e.lds == dynamic_lds && e.blocks > 0) return e.blocks;
+    Entry &last = seen[next++ % 16];
     int cus = 256, per_cu = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dynamic_lds) != hipSuccess || per_cu < 1) {
