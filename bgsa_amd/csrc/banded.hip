@@ -653,8 +653,10 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
         const int n_windows = __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2);
         unsigned long long dead_mask[G];
         int left, early;
+        // (the collector rows return the ONES of D0's bit 0 since row k where the others return the errors: turned around below)
+        constexpr bool COLL = false;
         if constexpr (FORM == 2 && G == 1)
-            banded_funnel64_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, static_cast<uint32_t>(band64 >> 32), cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
+            banded_funnel64s_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, static_cast<uint32_t>(band64 >> 32), cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         else if constexpr (FORM == 2)
             banded_funnel64_rows_asm_g2(st, M, voff, base, uniform_u64(s), n_windows, band, static_cast<uint32_t>(band64 >> 32), cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         else if constexpr (FORM == 1)
@@ -693,7 +695,9 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
                     vp |= static_cast<unsigned long long>(st[NS * gg + 1]) << 32;
                     vn |= static_cast<unsigned long long>(st[NS * gg + 3]) << 32;
                 }
-                uint32_t err = static_cast<uint32_t>(k) + st[NS * gg + NS - 1], best = err;
+                uint32_t counted = st[NS * gg + NS - 1];
+                if constexpr (COLL) counted = static_cast<uint32_t>(len > k ? len - k : len) - counted;   // rows counted - ones
+                uint32_t err = static_cast<uint32_t>(k) + counted, best = err;
                 for (int i = 0; i <= h; i++) {
                     err += static_cast<uint32_t>((vp >> i) & 1ull);
                     err -= static_cast<uint32_t>((vn >> i) & 1ull);

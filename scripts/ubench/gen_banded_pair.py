@@ -42,8 +42,9 @@ def regs(g):
     return {n: f"v{b + i}" for i, n in enumerate(NAMES)}
 
 
-def pair(g, x2="align", win="align"):
+def pair(g, x2="align", win="align", add64=False, coll=False):
     r = regs(g)
+    p2 = lambda lo: f"v[{r[lo][1:]}:{int(r[lo][1:]) + 1}]"   # the even-aligned pair that starts at register `lo`
     out = []
     if win == "align":
         out += [f"v_alignbit_b32 {r['wl']}, {r['e1']}, {r['e0']}, {S_SH}", f"v_alignbit_b32 {r['wh']}, {r['e2']}, {r['e1']}, {S_SH}"]
@@ -61,9 +62,14 @@ def pair(g, x2="align", win="align"):
         f"v_bitop3_b32 {r['xh']}, {r['wh']}, {MH}, {r['vnh']} bitop3:0x{T_X:02x}",
         f"v_and_b32 {r['tl']}, {r['xl']}, {r['vpl']}",
         f"v_and_b32 {r['th']}, {r['xh']}, {r['vph']}",
-        f"v_add_co_u32 {r['tl']}, vcc, {r['tl']}, {r['vpl']}",
-        "s_nop 1",                                                       # as the emitter pads the shipped row (VCC hazard)
-        f"v_addc_co_u32 {r['th']}, vcc, {r['th']}, {r['vph']}, vcc",
+    ]
+    if add64:               # gfx940+: one 64-bit (S0 << S1) + S2 in place of the carry pair (and no VCC hazard)
+        out += [f"v_lshl_add_u64 {p2('tl')}, {p2('tl')}, 0, {p2('vpl')}"]
+    else:
+        out += [f"v_add_co_u32 {r['tl']}, vcc, {r['tl']}, {r['vpl']}",
+                "s_nop 1",                                                       # as the emitter pads the shipped row (VCC hazard)
+                f"v_addc_co_u32 {r['th']}, vcc, {r['th']}, {r['vph']}, vcc"]
+    out += [
         f"v_bitop3_b32 {r['dl']}, {r['tl']}, {r['vpl']}, {r['xl']} bitop3:0x{T_D0:02x}",
         f"v_bitop3_b32 {r['dh']}, {r['th']}, {r['vph']}, {r['xh']} bitop3:0x{T_D0:02x}",
         f"v_bitop3_b32 {r['hpl']}, {r['dl']}, {r['vpl']}, {r['vnl']} bitop3:0x{T_HP:02x}",
@@ -76,17 +82,23 @@ def pair(g, x2="align", win="align"):
     elif x2 == "fast":
         out += [f"v_lshrrev_b32 {r['x2l']}, 1, {r['dl']}", f"v_and_b32 {r['n']}, 1, {r['dh']}", f"v_sub_u32 {r['n']}, 0, {r['n']}",
                 f"v_bitop3_b32 {r['x2l']}, {r['x2l']}, {r['n']}, {TOP} bitop3:0x{T_INS:02x}"]
+    elif x2 == "b64":      # one 64-bit shift for both halves
+        out += [f"v_lshrrev_b64 {p2('x2l')}, 1, {p2('dl')}"]
     else:
         out += [f"v_lshrrev_b32 {r['x2l']}, 1, {r['dl']}"]
+    if x2 != "b64":
+        out += [f"v_lshrrev_b32 {r['x2h']}, 1, {r['dh']}"]
     out += [
-        f"v_lshrrev_b32 {r['x2h']}, 1, {r['dh']}",
         f"v_and_b32 {r['vnl']}, {r['x2l']}, {r['hpl']}",
         f"v_and_b32 {r['vnh']}, {r['x2h']}, {r['hph']}",
         f"v_bitop3_b32 {r['vpl']}, {r['hpl']}, {r['x2l']}, {r['hnl']} bitop3:0x{T_VP:02x}",
         f"v_bitop3_b32 {r['vph']}, {r['hph']}, {r['x2h']}, {r['hnh']} bitop3:0x{T_VP:02x}",
-        f"v_bitop3_b32 {r['e']}, {r['dl']}, 1, 1 bitop3:0x{T_E:02x}",
-        f"v_add_u32 {r['acc']}, {r['acc']}, {r['e']}",
     ]
+    if coll:                # the lowest diagonal's D0 bits collected by a funnel shift (popcount once per 32 rows, in an event)
+        out += [f"v_alignbit_b32 {r['acc']}, {r['dl']}, {r['acc']}, 1"]
+    else:
+        out += [f"v_bitop3_b32 {r['e']}, {r['dl']}, 1, 1 bitop3:0x{T_E:02x}",
+                f"v_add_u32 {r['acc']}, {r['acc']}, {r['e']}"]
     return out
 
 
@@ -117,6 +129,15 @@ KERNELS = [
     ("pair_win1", pair(0, win="one"), 1),
     ("pair_tok2", pair(0) + pair(0, win="one"), 2),                     # a two-row token: full window, then the shifted one
     ("pair_tok2_zip2", zip2(lambda g: pair(g) + pair(g, win="one")), 4),
+    ("pair_coll", pair(0, coll=True), 1),                               # 21: error bits collected by a funnel shift
+    ("pair_sh64", pair(0, x2="b64"), 1),                                # 21: D0 >> 1 as one v_lshrrev_b64
+    ("pair_add64", pair(0, add64=True), 1),                             # 21: the carry pair as one v_lshl_add_u64
+    ("pair_19", pair(0, x2="b64", add64=True, coll=True), 1),           # 19: all three
+    ("pair_19_zip2", zip2(lambda g: pair(g, x2="b64", add64=True, coll=True)), 2),
+    ("pair_sh64_top", (lambda b: b[:2] + [b[15]] + b[16:20] + b[2:15] + b[20:])(pair(0, x2="b64")), 1),   # the ROTATED row: the windows'
+    # funnel shifts and the previous row's D0 >> 1 adjacent at the top (one slow-class group per row), then the previous row's VN / VP, then this row
+    ("pair_sh64_top_zip2", zip2(lambda g: (lambda b: b[:2] + [b[15]] + b[16:20] + b[2:15] + b[20:])(pair(g, x2="b64"))), 2),
+    ("pair_sh64_zip2", zip2(lambda g: pair(g, x2="b64")), 2),
     ("pair_x2only", pair(0, win="fake"), 1),                            # ONE funnel shift left in 22 instructions
     ("pair_allfast", pair(0, x2="fake", win="fake"), 1),
     ("pair_allfast_zip2", zip2(lambda g: pair(g, x2="fake", win="fake")), 2),

@@ -483,3 +483,37 @@ def test_banded_funnel_rows_for_two_groups_equal_two_single_rows(wide):
             want = [x.copy() for x in st[g * n_state:(g + 1) * n_state]]
             one.simulate(want, eq[g * n_eq:(g + 1) * n_eq], scalars=sc)
             assert all(np.array_equal(a, b) for a, b in zip(want, got[g * n_state:(g + 1) * n_state])), (wide, trial, g)
+
+
+def _banded_pairs(rng, n, length, k, mode):
+    query = rng.choice(list(b"ACGT"), length).astype(np.uint8)
+    subs = np.empty((n, length), np.uint8)
+    for i in range(n):
+        if mode == "random" or (mode == "mix" and i % 2):
+            subs[i] = rng.choice(list(b"ACGTN"), length, p=[.24, .24, .24, .24, .04])
+        else:
+            s = query.copy()
+            for p in rng.integers(0, length, rng.integers(0, k + 3)):
+                s[p] = rng.choice(list(b"ACGT"))
+            subs[i] = s
+    return subs, query
+
+
+@pytest.mark.parametrize("k,length", [(13, 150), (15, 150), (14, 100), (15, 33), (13, 64), (16, 150), (24, 150), (31, 150), (31, 200), (20, 97), (31, 64)])
+def test_banded_collector_rows_score_like_the_counting_rows(k, length):
+    """Round 4: the funnel-shift rows with the error count left to the events (banded_body_coll: 10 VALU, banded_body64_coll: 19
+    — D0 in a fixed register pair shifted by ONE v_lshrrev_b64, its bit 0 collected instead of added, the pair's carry add ONE
+    v_lshl_add_u64) with the events' popcount bookkeeping, for one and two groups per wave, against the counting rows (12 / 22
+    VALU), which the tests above pin to the oracle.  Planted, mixed and random pairs: tests, latches and early stops included."""
+    rng = np.random.default_rng(1000 * k + length)
+    wide = k > 15
+    assert R.banded_funnel_body(1, wide, coll=True).valu_count() == (19 if wide else 10)
+    assert R.banded_funnel_body(1, True, coll=True, add64=False).valu_count() == 20
+    assert R.count_hazard_nops(R.schedule(R.banded_funnel_body(2, wide, coll=True), 8)) == 0
+    for mode in ("planted", "mix", "random"):
+        subs, query = _banded_pairs(rng, 64, length, k, mode)
+        want = R.banded_simulate(subs, query, k)
+        for groups in (1, 2):
+            assert np.array_equal(R.banded_simulate_coll(subs, query, k, groups=groups), want), (mode, groups)
+        if wide:
+            assert np.array_equal(R.banded_simulate_coll(subs, query, k, groups=1, add64=False), want), mode
