@@ -532,7 +532,8 @@ __global__ __launch_bounds__(256) void banded_asm_kernel(
 // 13 .. 15 (32-bit band) / 16 .. 31 (64-bit pair) — banded_funnel{32,64}_rows_asm_g2: what two groups per wave, the woven dispatch,
 // the solid-survivor rule and the task counter are worth to the rows that have to keep their v_alignbit.  Those
 // forms keep three / four match-string words per class and group (the last one the prefetch target) and use the funnel-shift
-// dense pass (banded_finish_pair<T>).
+// dense pass (banded_finish_pair<T>).  The pair row of the default (one group per wave) shifts D0 with ONE v_lshrrev_b64 on a fixed
+// register pair (banded_funnel64s_rows_asm_g1: 21 VALU per row, -2 %; LABNOTES 9.6 has what else was tried on these rows).
 template <int G, bool DYN = false, int FORM = 0>
 __global__ __launch_bounds__(256) void banded_cut_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ mext, int8_t *__restrict__ out,
@@ -653,8 +654,6 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
         const int n_windows = __builtin_amdgcn_readfirstlane(stream_stride_bytes / 8 - 2);
         unsigned long long dead_mask[G];
         int left, early;
-        // (the collector rows return the ONES of D0's bit 0 since row k where the others return the errors: turned around below)
-        constexpr bool COLL = false;
         if constexpr (FORM == 2 && G == 1)
             banded_funnel64s_rows_asm_g1(st, M, voff, base, uniform_u64(s), n_windows, band, static_cast<uint32_t>(band64 >> 32), cut_rows, limit, push_row, push_row_solid, solid_limit, push_max, dead_mask, left, early);
         else if constexpr (FORM == 2)
@@ -695,9 +694,7 @@ __global__ __launch_bounds__(256) void banded_cut_kernel(
                     vp |= static_cast<unsigned long long>(st[NS * gg + 1]) << 32;
                     vn |= static_cast<unsigned long long>(st[NS * gg + 3]) << 32;
                 }
-                uint32_t counted = st[NS * gg + NS - 1];
-                if constexpr (COLL) counted = static_cast<uint32_t>(len > k ? len - k : len) - counted;   // rows counted - ones
-                uint32_t err = static_cast<uint32_t>(k) + counted, best = err;
+                uint32_t err = static_cast<uint32_t>(k) + st[NS * gg + NS - 1], best = err;
                 for (int i = 0; i <= h; i++) {
                     err += static_cast<uint32_t>((vp >> i) & 1ull);
                     err -= static_cast<uint32_t>((vn >> i) & 1ull);

@@ -553,7 +553,7 @@ def gen_banded_function(wide: bool, phase: bool = False) -> str:
 """
 
 
-def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, sh64: bool = False) -> str:
+def gen_banded_cut_function(groups: int, form: str = "cut", sh64: bool = False) -> str:
     """form = "cut": row loop of the one-word-window banded kernel (k <= 12; rows_ir.banded_cut_body), for one or two subject
     groups per wave.  form = "funnel32" / "funnel64" (round 4): the same loop — two groups per wave sharing every dispatch,
     shift counter and event, the next token's dispatch woven under the last row, solid-survivor pushes — around the
@@ -566,26 +566,21 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
     cutrows, i.e. the window moves up by cutrows bits in place.  The row's shift count restarts at either.  (Until
     round 3's last change the loop kept four registers: the cut window apart from A, and the word after B prefetched a
     whole advance ahead: 91 VGPRs = five waves per SIMD; with two registers per class and group the kernel holds 73 = six.)
-    coll (funnel forms, round 4's second step): the collector rows (rows_ir.banded_body_coll / banded_body64_coll: 10 / 19
-    VALU instead of 12 / 22) — D0 sits in a FIXED aligned register pair (v_lshrrev_b64 shifts it and, in the 32-bit row, collects
-    its bit 0; the pair row's sum and VP are fixed pairs too, for v_lshl_add_u64), the per-row error add is gone, and the
-    events count instead: state "errors" = the D0 bit-0 ONES folded so far (popcount(collector) at every advance, and at
-    L_done), a test compares ones + popcount(collector) with rows since row k - limit.  The caller turns ones into errors.
+    sh64 (funnel64): rows_ir.banded_body64_sh64 — D0 of the pair row sits in a FIXED aligned register pair (clobbered by name; the
+    compiler keeps clear of it) and D0 >> 1 is ONE v_lshrrev_b64 instead of a funnel shift and a plain one: 21 VALU per row.
     With two groups the tests, the push decision and the early exit look at both: the wave stops when all 128 lanes
     are past the limit."""
     G = groups
     assert form in ("cut", "funnel32", "funnel64")
     funnel, wide = form != "cut", form == "funnel64"
-    assert (funnel or not coll) and (wide or not sh64) and not (coll and sh64)
-    body = R.banded_cut_body(G) if not funnel else R.schedule(R.banded_funnel_body(G, wide, coll=coll, sh64=sh64), 8)
+    assert wide or not sh64
+    body = R.banded_cut_body(G) if not funnel else R.schedule(R.banded_funnel_body(G, wide, sh64=sh64), 8)
+    PBASE = 2                                            # first fixed VGPR of the 'P' registers (rows_ir.Body)
+    n_fixed = 2 * G if sh64 else 0
+    P = lambda n: f"v{PBASE + n}"
     per_state = 5 if wide else 3
-    ir_state = 6 if (wide and coll) else per_state      # the pair's collector is an IR state register, here a temporary of the loop
     n_state = per_state * G
     acc = [per_state * g + per_state - 1 for g in range(G)]
-    PBASE = 2                                            # first fixed VGPR (clobbered by name: the compiler keeps clear of them)
-    n_fixed = (6 if wide else 2) * G if coll else (2 * G if sh64 else 0)   # sh64: D0 of the pair row in a fixed pair, nothing else changes
-    P = lambda n: f"v{PBASE + n}"
-    COLL = [] if not coll else ([f"%[c{g}]" for g in range(G)] if wide else [P(2 * g) for g in range(G)])
     n_m = 2 if not funnel else (4 if wide else 3)      # match-string words per class and group (funnel: the last = prefetch target)
     n_eq = 3 if wide else 2                            # ... that the row reads
     slot_of, n_slots = body.allocate_temps()
@@ -596,19 +591,13 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
     S_BASE = [f"s[{80 + 2 * c}:{81 + 2 * c}]" for c in range(5)]
     S_CHUNK, S_PUSHROW, S_PUSHMAX, S_EARLY = "s92", "s93", "s94", "s95"
     S_PUSHSOLID, S_THRSOLID = "s56", "s55"
-    S_NEED, S_KTHR, S_KSOLID = "s52", "s53", "s54"      # coll: ones needed to stay within the limit; k + limit; k + solid limit
-    clobbers = ["s55", "s56", "s57", "s58", "s59"] + CLOBBERS[:-3] + [f"s{i}" for i in range(72, 100)] + ["vcc", "scc", "memory"]
-    if coll:
-        clobbers = ["s52", "s53", "s54"] + clobbers
-    clobbers = [P(i) for i in range(n_fixed)] + clobbers
+    clobbers = [P(i) for i in range(n_fixed)] + ["s55", "s56", "s57", "s58", "s59"] + CLOBBERS[:-3] + [f"s{i}" for i in range(72, 100)] + \
+               ["vcc", "scc", "memory"]
 
     def reg_for(c: int):
         def reg(name: str) -> str:
             if name.startswith("P"):
                 return P(int(name[1:]))
-            if name.startswith("S") and ir_state != per_state:
-                g_, j = divmod(int(name[1:]), ir_state)
-                return f"%[c{g_}]" if j == 5 else f"%[s{per_state * g_ + j}]"
             if name.startswith("S"):
                 return f"%[s{name[1:]}]"
             if name.startswith("E") and funnel:
@@ -642,17 +631,6 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
 
     def test(tag: str) -> list[str]:
         """err > limit on every lane of every group -> vcc (group 0), S_VCC1 (group 1); alive masks; scc = any alive."""
-        if coll:
-            # errors = rows since row k - ones: past the limit  <=>  ones < rows so far - (k + limit); %[t<g>] = ones, kept for push_or
-            out = [f"s_lshl_b32 {S_NEED}, {S_CHUNK}, 5",
-                   f"s_add_u32 {S_NEED}, {S_NEED}, {S_SH}",
-                   f"s_sub_u32 {S_NEED}, {S_NEED}, {S_KTHR}",
-                   f"s_max_i32 {S_NEED}, {S_NEED}, 0"]
-            out += [f"v_bcnt_u32_b32 %[t{g}], {COLL[g]}, %[s{acc[g]}]" for g in range(G)]
-            out += [f"v_cmp_gt_u32 vcc, {S_NEED}, %[t0]"]
-            if G == 2:
-                out += [f"v_cmp_gt_u32_e64 {S_VCC1}, {S_NEED}, %[t1]", "s_nop 1"]
-            return out
         out = [f"v_cmp_lt_u32 vcc, {S_THR}, %[s{acc[0]}]"]
         if G == 2:
             out += [f"v_cmp_lt_u32_e64 {S_VCC1}, {S_THR}, %[s{acc[1]}]", "s_nop 1"]
@@ -694,16 +672,9 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
             f"s_cbranch_scc0 {label_no}",
             f"s_cmp_ge_u32 {S_CNT}, {S_PUSHROW}",
             f"s_cbranch_scc1 L_push_{tag}_%=",
+            f"v_cmp_ge_u32 vcc, {S_THRSOLID}, %[s{acc[0]}]",
         ]
-        if coll:     # a solid survivor: errors <= solid limit  <=>  ones (%[t<g>], from the test just run) >= rows so far - (k + solid limit)
-            out += [f"s_sub_u32 {S_NEED}, {S_CNT}, {S_KSOLID}",
-                    f"s_max_i32 {S_NEED}, {S_NEED}, 0",
-                    f"v_cmp_le_u32 vcc, {S_NEED}, %[t0]"]
-            if G == 2:
-                out += [f"v_cmp_le_u32_e64 {S_ANY}, {S_NEED}, %[t1]", "s_nop 1", f"s_or_b64 vcc, vcc, {S_ANY}"]
-        else:
-            out += [f"v_cmp_ge_u32 vcc, {S_THRSOLID}, %[s{acc[0]}]"]
-        if G == 2 and not coll:
+        if G == 2:
             out += [f"v_cmp_ge_u32_e64 {S_ANY}, {S_THRSOLID}, %[s{acc[1]}]", "s_nop 1", f"s_or_b64 vcc, vcc, {S_ANY}"]
         out += [
             "s_cmp_lg_u64 vcc, 0",
@@ -732,12 +703,6 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
     ]
     asm += [f"s_mov_b64 {S_DEAD[g]}, 0" for g in range(G)]
     asm += [f"s_mov_b64 {S_BASE[c]}, %[base{c}]" for c in range(5)]
-    if coll:
-        asm += [f"s_add_u32 {S_KTHR}, %[kk], {S_THR}", f"s_add_u32 {S_KSOLID}, %[kk], {S_THRSOLID}"]
-        asm += [f"v_mov_b32 {COLL[g]}, 0" for g in range(G)]
-        if wide:     # VP lives in its fixed pair inside the loop
-            for g in range(G):
-                asm += [f"v_mov_b32 {P(6 * g + 4)}, %[s{per_state * g}]", f"v_mov_b32 {P(6 * g + 5)}, %[s{per_state * g + 1}]"]
     asm += [
         f"s_getpc_b64 {S_PC}",
         "L_anchor_%=:",
@@ -835,16 +800,12 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
         "s_cbranch_scc0 L_ev_adv_%=",
     ]
     asm += [f"v_mov_b32 %[s{a}], 0" for a in acc]
-    asm += [f"v_mov_b32 {COLL[g]}, 0" for g in range(G) if coll]
     asm += [
         "L_ev_adv_%=:",
         f"s_bitcmp1_b32 {S_ARG}, 1",          # bit 1: next 32 rows
         "s_cbranch_scc0 L_ev_cut_%=",
         "s_waitcnt vmcnt(0)",
     ]
-    if coll:                 # the collector holds the last (at most 32) rows' D0 bit 0: fold its ones into the count
-        for g in range(G):
-            asm += [f"v_bcnt_u32_b32 %[s{acc[g]}], {COLL[g]}, %[s{acc[g]}]", f"v_mov_b32 {COLL[g]}, 0"]
     for g in range(G):       # (vmcnt(0): a word fetched by the previous advance that no cut has waited for yet)
         for w in range(n_m - 1):
             asm += [f"v_mov_b32 %[m{w}_{c}_{g}], %[m{w + 1}_{c}_{g}]" for c in range(5)]
@@ -874,18 +835,11 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
     asm += ["L_ev_cut_done_%=:", f"s_add_u32 {S_CUT}, {S_CUT}, {S_CUTROWS}", "L_ev_out_%=:"]
     asm += disp()
     asm += done("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    if coll:
-        asm += [f"v_bcnt_u32_b32 %[s{acc[g]}], {COLL[g]}, %[s{acc[g]}]" for g in range(G)]
-        if wide:
-            for g in range(G):
-                asm += [f"v_mov_b32 %[s{per_state * g}], {P(6 * g + 4)}", f"v_mov_b32 %[s{per_state * g + 1}], {P(6 * g + 5)}"]
     asm += [f"s_mov_b64 %[dead{g}], {S_DEAD[g]}" for g in range(G)]
     asm.append(f"s_mov_b32 %[early], {S_EARLY}")
 
     text = "\n".join(f'        "{line}\\n\\t"' if not line.endswith(":") else f'        "{line}\\n"' for line in asm)
     outs = [f'[s{i}] "+v"(state[{i}])' for i in range(n_state)]
-    if coll and wide:
-        outs += [f'[c{g}] "=&v"(collector[{g}])' for g in range(G)]
     outs += [f'[m{w}_{c}_{g}] "+v"(M[{g}][{c}][{w}])' for g in range(G) for c in range(5) for w in range(n_m)]
     outs += [f'[voff{g}] "+v"(voff[{g}])' for g in range(G)]
     outs += [f'[dead{g}] "=s"(dead[{g}])' for g in range(G)]
@@ -895,43 +849,17 @@ def gen_banded_cut_function(groups: int, form: str = "cut", coll: bool = False, 
           ['[thr] "s"(limit)', '[cutrows] "s"(cut_rows)',
            '[pushrow] "s"(push_row)', '[pushmax] "s"(push_max)', '[pushsolid] "s"(push_row_solid)', '[solidthr] "s"(solid_limit)']
     ins += [f'[base{c}] "s"(base[{c}])' for c in range(5)]
-    if coll:
-        ins += ['[kk] "s"(k_rows)']
     clob = ", ".join(f'"{x}"' for x in clobbers)
-    if funnel and coll:
-        bits = 64 if wide else 32
-        coll_decl = f" uint32_t collector[{G}];" if wide else ""
-        return f"""
-// Funnel-shift banded rows with the error count left to the events ({bits}-bit band: thresholds {'16 .. 31' if wide else '13 .. 15'}), {G} subject group{'s' if G > 1 else ''} per wave:
-// {body.valu_count()} VALU per row ({sum(op.kind in ('alignbit', 'shr64', 'add64') for op in body.ops)} slow-class among them), {n_slots} temporaries, fixed registers {P(0)} .. {P(n_fixed - 1)}
-// (aligned pairs for v_lshrrev_b64{' / v_lshl_add_u64' if wide else ''}; clobbered by name).  As banded_funnel{bits}_rows_asm_g{G}, except: on return state[{per_state}g + {per_state - 1}] = the ONES of D0's
-// bit 0 since row k (the caller's errors = rows since row k - ones); k_rows = k.
-__device__ __forceinline__ void banded_funnel{bits}c_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][{n_m}], uint32_t (&voff)[{G}],
-                                                       const unsigned long long (&base)[5],
-                                                       const unsigned long long stream, const int n_windows,
-                                                       const uint32_t band_mask, {'const uint32_t band_mask_hi, ' if wide else ''}const uint32_t cut_rows,
-                                                       const uint32_t limit, const uint32_t push_row, const uint32_t push_row_solid, const uint32_t solid_limit,
-                                                       const uint32_t push_max, const uint32_t k_rows, unsigned long long (&dead)[{G}],
-                                                       int &left, int &early)
-{{
-    uint32_t tmp[{max(n_slots, 1)}];{coll_decl}
-    asm volatile(
-{text}
-        : {", ".join(outs)}
-        : {", ".join(ins)}
-        : {clob});
-}}
-"""
     if funnel:
         bits = 64 if wide else 32
         sfx = "s" if sh64 else ""
+        note = f"  D0 >> 1 is ONE v_lshrrev_b64 on the fixed pair {P(0)}:{P(1)} (clobbered by name)." if sh64 else ""
         return f"""
 // Funnel-shift banded rows ({bits}-bit band: thresholds {'16 .. 31' if wide else '13 .. 15'}), {G} subject group{'s' if G > 1 else ''} per wave: {body.valu_count()} VALU per row
 // ({sum(op.kind in ('alignbit',) for op in body.ops)} funnel shifts among them), {n_slots} temporaries.  state[{per_state}g ..] = {{VP, VN, errors since row k}} of group g
 // (VP lo / hi, VN lo / hi, errors when the band is a pair); M[g][c] = {n_m} consecutive 32-bit words of class c's offset match string, the last
 // one the prefetch target; voff[g] = byte offset of the next word to fetch relative to base[c] (group 1: the group stride included);
-// dead / left / early and the push rules as banded_cut_rows_asm_g{G} (cut_rows is not used: the stream carries no cut events).
-// {"(sh64: D0 >> 1 is ONE v_lshrrev_b64 on the fixed pair " + P(0) + ":" + P(1) + ", clobbered by name.)" if sh64 else ""}
+// dead / left / early and the push rules as banded_cut_rows_asm_g{G} (cut_rows is not used: the stream carries no cut events).{note}
 __device__ __forceinline__ void banded_funnel{bits}{sfx}_rows_asm_g{G}(uint32_t (&state)[{n_state}], uint32_t (&M)[{G}][5][{n_m}], uint32_t (&voff)[{G}],
                                                        const unsigned long long (&base)[5],
                                                        const unsigned long long stream, const int n_windows,
@@ -1594,8 +1522,6 @@ def main() -> int:
     (here / "banded_rows_gen.inc").write_text(head + gen_banded_function(False) + gen_banded_function(False, phase=True) + gen_banded_function(True) +
                                               gen_banded_chunk_function() + gen_banded_cut_function(1) + gen_banded_cut_function(2) +
                                               gen_banded_cut_function(2, "funnel32") + gen_banded_cut_function(2, "funnel64") +
-                                              gen_banded_cut_function(1, "funnel64") +
-                                              gen_banded_cut_function(2, "funnel32", coll=True) + gen_banded_cut_function(1, "funnel64", coll=True) +
                                               gen_banded_cut_function(1, "funnel64", sh64=True))
     return 0
 

@@ -93,11 +93,6 @@ class Body:
         self.ops.append(Op("shr64", hi, (hi, lo), 0, lo))
         return hi
 
-    def ADD64(self, hi, lo, bhi, blo):
-        """{hi, lo} += {bhi, blo} as ONE v_lshl_add_u64 (shift 0) on aligned register pairs: no VCC, no hazard."""
-        self.ops.append(Op("add64", hi, (hi, lo, bhi, blo), 0, lo))
-        return hi
-
     def MATCH3(self, d, b0, b1, b2, wild=False):
         """d = columns whose 3-bit character code (b2 b1 b0) equals the row's class (0..4 = A C G T
         N): a v_bitop3 whose truth table depends on which of the five body copies it sits in.
@@ -226,12 +221,6 @@ class Body:
                 pair = ((s[0].astype(np.uint64) << np.uint64(32)) | s[1].astype(np.uint64)) >> np.uint64(1)
                 wr(op.dst, pair >> np.uint64(32))
                 wr(op.dst2, pair & np.uint64(0xFFFFFFFF))
-            elif k == "add64":
-                a = (s[0].astype(np.uint64) << np.uint64(32)) | s[1].astype(np.uint64)
-                b_ = (s[2].astype(np.uint64) << np.uint64(32)) | s[3].astype(np.uint64)
-                tot = a + b_                       # wraps mod 2^64, as the instruction does
-                wr(op.dst, tot >> np.uint64(32))
-                wr(op.dst2, tot & np.uint64(0xFFFFFFFF))
             else:
                 raise ValueError(k)
 
@@ -269,15 +258,10 @@ class Body:
             elif k == "addcz": lines.append(f"v_addc_co_u32 {d}, vcc, 0, {r[0]}, vcc")
             elif k == "subbz": lines.append(f"v_subbrev_co_u32 {d}, vcc, 0, {r[0]}, vcc")
             elif k == "minu": lines.append(f"v_min_u32 {d}, {r[0]}, {r[1]}")
-            elif k in ("shr64", "add64"):
-                def pair(hi, lo):
-                    h, l = reg_name(hi), reg_name(lo)
-                    assert h[0] == "v" and l[0] == "v" and int(h[1:]) == int(l[1:]) + 1 and int(l[1:]) % 2 == 0, (h, l)
-                    return f"v[{l[1:]}:{h[1:]}]"
-                if k == "shr64":
-                    lines.append(f"v_lshrrev_b64 {pair(op.srcs[0], op.srcs[1])}, 1, {pair(op.srcs[0], op.srcs[1])}")
-                else:
-                    lines.append(f"v_lshl_add_u64 {pair(op.srcs[0], op.srcs[1])}, {pair(op.srcs[0], op.srcs[1])}, 0, {pair(op.srcs[2], op.srcs[3])}")
+            elif k == "shr64":
+                h, l = reg_name(op.srcs[0]), reg_name(op.srcs[1])
+                assert h[0] == "v" and l[0] == "v" and int(h[1:]) == int(l[1:]) + 1 and int(l[1:]) % 2 == 0, (h, l)
+                lines.append(f"v_lshrrev_b64 v[{l[1:]}:{h[1:]}], 1, v[{l[1:]}:{h[1:]}]")
             else:
                 raise ValueError(k)
             since_vcc_write = 0 if k in ("add_co", "addc", "addcz", "subbz") else since_vcc_write + 1
@@ -754,69 +738,6 @@ def banded_body() -> Body:
     return b
 
 
-def banded_body_coll(g: int = 0) -> Body:
-    """banded_body with the error count left to the events (round 4): D0 is formed in the HIGH word of an aligned register
-    pair whose low word collects D0's bit 0 — `v_lshrrev_b64 pair, 1, pair` is D0 >> 1 AND the collector's shift, one
-    instruction in place of three (shift, ~D0 & 1, add): 10 VALU per row.  The row holds a v_alignbit anyway, so one more
-    slow-class instruction costs nothing, and a slow row's time goes with its instruction count
-    (profiles/r03_ubench_banded_mix.txt: 52.8 -> 41.8 cycles).  State: S0 = VP, S1 = VN, S2 = D0 bit-0 ONES folded so far
-    (the events fold popcount(collector) into it every 32 rows at the latest: errors = rows since row k - ones);
-    fixed pair g: P<2g> = the collector, P<2g+1> = D0."""
-    b = Body()
-    lo, hi = f"P{2 * g}", f"P{2 * g + 1}"
-    b.ALIGNBIT("w", "E1", "E0", "$sh")
-    b.BITOP3("x", "w", "$mask", "S1", lambda w, m, vn: (w & m) | vn)
-    b.AND("t", "x", "S0")
-    b.ADD("t", "t", "S0")
-    b.BITOP3(hi, "t", "S0", "x", lambda t, vp, x: (t ^ vp) | x)
-    b.BITOP3("hp", hi, "S0", "S1", lambda d, vp, vn: ~(d | vp) | vn)
-    b.AND("hn", hi, "S0")
-    b.SHR64(hi, lo)
-    b.AND("S1", hi, "hp")
-    b.BITOP3("S0", "hp", hi, "hn", lambda hp, x2, hn: ~(hp | x2) | hn)
-    return b
-
-
-def banded_body64_coll(g: int = 0, add64: bool = True) -> Body:
-    """banded_body64 with (i) D0 >> 1 as ONE v_lshrrev_b64 on the fixed pair (P<6g+1> : P<6g>) = (D0 hi : D0 lo), (ii) the
-    lowest diagonal's D0 bits collected by one funnel shift into S4 (popcount in the events, as banded_body_coll), (iii) with
-    add64 the carry pair as ONE v_lshl_add_u64 — which needs (X & VP) and VP as pairs too: P<6g+2/3> = the sum, P<6g+4/5> = VP
-    (S0 / S1 are then unused: VP lives in the fixed pair across rows; the loop moves it in and out).  19 VALU per row
-    (add64 = False: 20, VP stays in S0 / S1).  State: S0/S1 = VP lo/hi (add64: in P<6g+4/5>), S2/S3 = VN lo/hi, S4 = ones folded
-    so far, S5 = the collector."""
-    b = Body()
-    P = lambda i: f"P{6 * g + i}"
-    dl, dh, tl, th = P(0), P(1), P(2), P(3)
-    vpl, vph = (P(4), P(5)) if add64 else ("S0", "S1")
-    b.ALIGNBIT("wl", "E1", "E0", "$sh")
-    b.ALIGNBIT("wh", "E2", "E1", "$sh")
-    b.BITOP3("xl", "wl", "$mask_lo", "S2", lambda w, m, vn: (w & m) | vn)
-    b.BITOP3("xh", "wh", "$mask_hi", "S3", lambda w, m, vn: (w & m) | vn)
-    if add64:
-        b.AND(tl, "xl", vpl)
-        b.AND(th, "xh", vph)
-        b.ADD64(th, tl, vph, vpl)
-    else:
-        tl, th = "tl", "th"
-        b.AND(tl, "xl", vpl)
-        b.AND(th, "xh", vph)
-        b.ADD_CO(tl, tl, vpl)
-        b.ADDC(th, th, vph)
-    b.BITOP3(dl, tl, vpl, "xl", lambda t_, vp, x: (t_ ^ vp) | x)
-    b.BITOP3(dh, th, vph, "xh", lambda t_, vp, x: (t_ ^ vp) | x)
-    b.BITOP3("hpl", dl, vpl, "S2", lambda d, vp, vn: ~(d | vp) | vn)
-    b.BITOP3("hph", dh, vph, "S3", lambda d, vp, vn: ~(d | vp) | vn)
-    b.AND("hnl", dl, vpl)
-    b.AND("hnh", dh, vph)
-    b.ALIGNBIT("S5", dl, "S5", "$one")         # the collector takes D0's bit 0 at its top
-    b.SHR64(dh, dl)                             # D0 >> 1, both words
-    b.AND("S2", dl, "hpl")
-    b.AND("S3", dh, "hph")
-    b.BITOP3(vpl, "hpl", dl, "hnl", lambda hp, x2, hn: ~(hp | x2) | hn)
-    b.BITOP3(vph, "hph", dh, "hnh", lambda hp, x2, hn: ~(hp | x2) | hn)
-    return b
-
-
 def banded_body64_sh64(g: int = 0) -> Body:
     """banded_body64 with D0 >> 1 as ONE v_lshrrev_b64 on the fixed pair (P<2g+1> : P<2g>) = (D0 hi : D0 lo) in place of the funnel
     shift and the plain shift: 21 VALU per row; everything else — the error count included — as banded_body64."""
@@ -838,20 +759,18 @@ def banded_body64_sh64(g: int = 0) -> Body:
     return b
 
 
-def banded_funnel_body(groups: int = 1, wide: bool = False, coll: bool = False, add64: bool = True, sh64: bool = False) -> Body:
+def banded_funnel_body(groups: int = 1, wide: bool = False, sh64: bool = False) -> Body:
     """The funnel-shift rows (banded_body: k <= 15, banded_body64: k <= 31) for one or two subject groups per wave that share
     the stream and its scalar work, interleaved instruction by instruction as banded_cut_body's: group g's state is
     S<n*g .. n*g + n - 1> (n = 3: VP, VN, errors; wide n = 5: VP lo/hi, VN lo/hi, errors), its match-string words
     E<m*g .. m*g + m - 1> (m = 2, wide 3).  groups = 1 is banded_body() / banded_body64() itself.
-    coll: the collector rows (banded_body_coll / banded_body64_coll; wide n = 6), whose fixed registers are per group already."""
-    n_state, n_eq = ((6 if coll else 5), 3) if wide else (3, 2)
+    sh64: banded_body64_sh64 (its fixed register pair is per group already)."""
+    n_state, n_eq = (5, 3) if wide else (3, 2)
     per = []
     for g in range(groups):
         if sh64:
-            assert wide and not coll
+            assert wide
             base = banded_body64_sh64(g)
-        elif coll:
-            base = banded_body64_coll(g, add64) if wide else banded_body_coll(g)
         else:
             base = banded_body64() if wide else banded_body()
         ops = []
@@ -1219,89 +1138,6 @@ def banded_simulate(subjects: np.ndarray, query: np.ndarray, k: int, wide: bool 
         err = err + ((st[0] >> np.uint32(i)) & 1) - ((st[1] >> np.uint32(i)) & 1)
         best = np.minimum(best, err)
     return np.where(dead, 127, best).astype(np.int8)
-
-
-def banded_simulate_coll(subjects: np.ndarray, query: np.ndarray, k: int, groups: int = 1, add64: bool = True) -> np.ndarray:
-    """The funnel-shift kernels with the collector rows (banded_funnel_body(groups, wide, coll=True)) on the CPU, events as the
-    generated loop runs them: row k clears the ones count and the collector; every advance (32 rows) folds popcount(collector)
-    into the count and clears it; a test compares rows since row k - (count + popcount(collector)) with the limit."""
-    wide = k > 15
-    n, length = subjects.shape
-    assert n % groups == 0
-    code = np.zeros(256, dtype=np.uint8)
-    for ch, c in zip(b"ACGTN", range(5)):
-        code[ch] = c
-    mapped = code[subjects]
-    nwords = (length + 31) // 32 + 3
-    mext = np.zeros((5, nwords, n), dtype=np.uint32)
-    for p_ in range(length):
-        i = p_ + k + 1
-        for c in range(5):
-            mext[c, i // 32] |= (mapped[:, p_] == c).astype(np.uint32) << np.uint32(i % 32)
-    h = k
-    band = (1 << (2 * k + 1)) - 1
-    body = schedule(banded_funnel_body(groups, wide, coll=True, add64=add64), 8)
-    per = n // groups
-    sl = [slice(g * per, (g + 1) * per) for g in range(groups)]
-    ns, ne = (6, 3) if wide else (3, 2)
-    z = lambda: np.zeros(per, dtype=np.uint32)
-    st = [z() for _ in range(ns * groups)]
-    fixed = {f"P{i}": z() for i in range(6 * groups)}
-    ones = lambda g: st[ns * g + (4 if wide else 2)]
-    def coll(g, val=None):
-        if wide:
-            if val is not None: st[ns * g + 5] = val
-            return st[ns * g + 5]
-        if val is not None: fixed[f"P{2 * g}"] = val
-        return fixed[f"P{2 * g}"]
-    dead = np.zeros(n, dtype=bool)
-    wi, sh, done_rows, counted_from = 0, 0, 0, 0
-    qcode = code[query]
-    stopped = False
-    for kind, val in banded_tokens(length, k, phase=0):
-        if kind == "event":
-            if val & 4:
-                errs = [np.uint32(done_rows - counted_from) - (ones(g) + _popcount32(coll(g))) for g in range(groups)]
-                over = np.concatenate([e > np.uint32(h + 1) for e in errs])
-                if val & 8:
-                    dead = over.copy()
-                if over.all():
-                    stopped = True
-                    break
-            if val & 1:
-                counted_from = done_rows
-                for g in range(groups):
-                    st[ns * g + (4 if wide else 2)] = z()
-                    coll(g, z())
-            if val & 2:
-                wi, sh = wi + 1, 0
-                for g in range(groups):
-                    st[ns * g + (4 if wide else 2)] = ones(g) + _popcount32(coll(g))
-                    coll(g, z())
-        else:
-            c = int(qcode[val])
-            eq = [mext[c, wi + j, sl[g]] for g in range(groups) for j in range(ne)]
-            body.simulate(st, eq, scalars={"$sh": sh, "$mask": band & 0xFFFFFFFF, "$mask_lo": band & 0xFFFFFFFF,
-                                           "$mask_hi": band >> 32, "$one": 1}, fixed=fixed)
-            sh += 1
-            done_rows += 1
-    if stopped:
-        return np.full(n, 127, dtype=np.int8)
-    out = np.empty(n, dtype=np.int8)
-    for g in range(groups):
-        err = (np.uint32(done_rows - counted_from) - (ones(g) + _popcount32(coll(g)))).astype(np.int64) + k
-        if wide:
-            vpl, vph = (fixed[f"P{6 * g + 4}"], fixed[f"P{6 * g + 5}"]) if add64 else (st[ns * g], st[ns * g + 1])
-            vp = vpl.astype(np.uint64) | (vph.astype(np.uint64) << np.uint64(32))
-            vn = st[ns * g + 2].astype(np.uint64) | (st[ns * g + 3].astype(np.uint64) << np.uint64(32))
-        else:
-            vp, vn = st[ns * g].astype(np.uint64), st[ns * g + 1].astype(np.uint64)
-        best = err.copy()
-        for i in range(h + 1):
-            err = err + ((vp >> np.uint64(i)) & np.uint64(1)).astype(np.int64) - ((vn >> np.uint64(i)) & np.uint64(1)).astype(np.int64)
-            best = np.minimum(best, err)
-        out[sl[g]] = np.where(dead[sl[g]], 127, best).astype(np.int8)
-    return out
 
 
 def _popcount32(x: np.ndarray) -> np.ndarray:

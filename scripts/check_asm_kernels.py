@@ -35,7 +35,7 @@ def clobbered(func: str) -> set:
     if "banded_asm_kernel" in func:
         regs |= set(range(72, 96))
     if "banded_cut_kernel" in func:
-        regs |= set(range(72, 100)) | set(range(52, 60))
+        regs |= set(range(72, 100)) | {55, 56, 57, 58, 59}
     if "banded_chunk_kernel" in func:
         regs = set(range(60, 94))
     return regs

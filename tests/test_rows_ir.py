@@ -485,35 +485,20 @@ def test_banded_funnel_rows_for_two_groups_equal_two_single_rows(wide):
             assert all(np.array_equal(a, b) for a, b in zip(want, got[g * n_state:(g + 1) * n_state])), (wide, trial, g)
 
 
-def _banded_pairs(rng, n, length, k, mode):
-    query = rng.choice(list(b"ACGT"), length).astype(np.uint8)
-    subs = np.empty((n, length), np.uint8)
-    for i in range(n):
-        if mode == "random" or (mode == "mix" and i % 2):
-            subs[i] = rng.choice(list(b"ACGTN"), length, p=[.24, .24, .24, .24, .04])
-        else:
-            s = query.copy()
-            for p in rng.integers(0, length, rng.integers(0, k + 3)):
-                s[p] = rng.choice(list(b"ACGT"))
-            subs[i] = s
-    return subs, query
-
-
-@pytest.mark.parametrize("k,length", [(13, 150), (15, 150), (14, 100), (15, 33), (13, 64), (16, 150), (24, 150), (31, 150), (31, 200), (20, 97), (31, 64)])
-def test_banded_collector_rows_score_like_the_counting_rows(k, length):
-    """Round 4: the funnel-shift rows with the error count left to the events (banded_body_coll: 10 VALU, banded_body64_coll: 19
-    — D0 in a fixed register pair shifted by ONE v_lshrrev_b64, its bit 0 collected instead of added, the pair's carry add ONE
-    v_lshl_add_u64) with the events' popcount bookkeeping, for one and two groups per wave, against the counting rows (12 / 22
-    VALU), which the tests above pin to the oracle.  Planted, mixed and random pairs: tests, latches and early stops included."""
-    rng = np.random.default_rng(1000 * k + length)
-    wide = k > 15
-    assert R.banded_funnel_body(1, wide, coll=True).valu_count() == (19 if wide else 10)
-    assert R.banded_funnel_body(1, True, coll=True, add64=False).valu_count() == 20
-    assert R.count_hazard_nops(R.schedule(R.banded_funnel_body(2, wide, coll=True), 8)) == 0
-    for mode in ("planted", "mix", "random"):
-        subs, query = _banded_pairs(rng, 64, length, k, mode)
-        want = R.banded_simulate(subs, query, k)
-        for groups in (1, 2):
-            assert np.array_equal(R.banded_simulate_coll(subs, query, k, groups=groups), want), (mode, groups)
-        if wide:
-            assert np.array_equal(R.banded_simulate_coll(subs, query, k, groups=1, add64=False), want), mode
+def test_banded_pair_row_with_one_64_bit_shift_equals_the_shipped_pair_row():
+    """Round 4: banded_body64_sh64 — D0 of the pair row in a fixed aligned register pair, D0 >> 1 as ONE v_lshrrev_b64 (21 VALU
+    instead of 22; the kernel of thresholds 16 .. 31 runs it) — is banded_body64 (pinned to the oracle above) on every state."""
+    rng = np.random.default_rng(64)
+    one, new = R.banded_body64(), R.schedule(R.banded_funnel_body(1, True, sh64=True), 8)
+    assert new.valu_count() == one.valu_count() - 1 == 21 and R.count_hazard_nops(new) == 0
+    assert sum(op.kind == "shr64" for op in new.ops) == 1 and sum(op.kind == "alignbit" for op in new.ops) == 2
+    text = new.emit_asm(lambda n: {"P0": "v2", "P1": "v3"}.get(n, "v9"))
+    assert "v_lshrrev_b64 v[2:3], 1, v[2:3]" in text
+    for trial in range(50):
+        st = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(5)]
+        eq = [rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(3)]
+        sc = {"$sh": int(rng.integers(0, 32)), "$mask_lo": 0xFFFFFFFF, "$mask_hi": int(rng.integers(1, 2**31)), "$one": 1}
+        want, got = [x.copy() for x in st], [x.copy() for x in st]
+        one.simulate(want, eq, scalars=sc)
+        new.simulate(got, eq, scalars=sc, fixed={})
+        assert all(np.array_equal(a, b) for a, b in zip(want, got)), trial
