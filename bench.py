@@ -117,7 +117,10 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
             return R.banded_phase_body().valu_count()     # the band held in place (A/B alternative, k <= 11)
         if impl == "" and R.banded_cut_rows(k):
             return R.banded_cut_body(1).valu_count()      # one-word windows (per group and row, whatever the groups per wave)
-        return (R.banded_body() if k <= 15 else R.banded_body64()).valu_count()
+        if k <= 15:
+            return R.banded_body().valu_count()
+        one_shift = impl == "" and os.environ.get("BGSA_BANDED_PAIR_LOOP", "1") == "1"    # the default loop's pair row (round 4)
+        return (R.banded_body64_sh64() if one_shift else R.banded_body64()).valu_count()
     return None
 
 
