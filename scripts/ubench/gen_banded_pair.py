@@ -138,6 +138,8 @@ KERNELS = [
     # funnel shifts and the previous row's D0 >> 1 adjacent at the top (one slow-class group per row), then the previous row's VN / VP, then this row
     ("pair_sh64_top_zip2", zip2(lambda g: (lambda b: b[:2] + [b[15]] + b[16:20] + b[2:15] + b[20:])(pair(g, x2="b64"))), 2),
     ("pair_sh64_zip2", zip2(lambda g: pair(g, x2="b64")), 2),
+    ("pair_sh64_narrow", (lambda b, r: [b[0], f"v_lshrrev_b32 {r['wh']}, {S_SH}, {r['e1']}"] + b[2:])(pair(0, x2="b64"), regs(0)), 1),   # the
+    # high window by a plain shift: what a row may do while the band's high word does not reach into the third match word (row mod 32 <= 63 - 2k)
     ("pair_x2only", pair(0, win="fake"), 1),                            # ONE funnel shift left in 22 instructions
     ("pair_allfast", pair(0, x2="fake", win="fake"), 1),
     ("pair_allfast_zip2", zip2(lambda g: pair(g, x2="fake", win="fake")), 2),
