@@ -1314,7 +1314,11 @@ BITPAL_SCHEDULE_WINDOW = int(__import__('os').environ.get('BGSA_GEN_BITPAL_WINDO
 # 6,893 -> 6,854 ms and is on; one addition chain per class instead of two — same count, 13 -> 9 chains — measured 6,893 -> 6,949 ms
 # (and the chip held a lower clock under it) and is OFF
 BITPAL_ONE_CHAIN = __import__('os').environ.get('BGSA_GEN_BITPAL_ONE_CHAIN', '0') != '0'
-BITPAL_INLINE_LE = __import__('os').environ.get('BGSA_GEN_BITPAL_INLINE_LE', '1') != '0' 
+BITPAL_INLINE_LE = __import__('os').environ.get('BGSA_GEN_BITPAL_INLINE_LE', '1') != '0'
+# round 4, second step: new u = max(w, u) - v_in needs no clamp (see bitpal_scores_body: "the cell identity"); '0' builds the
+# previous form, new u = max(0, max(W, u) - v_in), for A/B
+BITPAL_CELL_MAX = __import__('os').environ.get('BGSA_GEN_BITPAL_CELL_MAX', '1') != '0'
+
 
 
 class _Bool:
@@ -1422,7 +1426,9 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
         i = 0
         while i < B and (D >> i) & 1:      # trailing one bits of the constant: always satisfied
             i += 1
-        if i >= B:
+        if BITPAL_CELL_MAX:
+            pass                               # max_planes() takes max(w, u) from the first subtract's borrow: nobody reads "u <= D"
+        elif i >= B:
             anym[w] = bx.op3(lambda e, _e, __e: ~e, E(w), E(w), E(w), "any")          # every u is <= D
         else:
             r = None
@@ -1488,20 +1494,26 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     # ---- w planes, v = max(0, w - u) = (w + ~u + 1) where that does not borrow, else 0 ------------------
     lit = {"reg": lambda x: x, "not": lambda x: ~x, "zero": lambda x: 0, "one": lambda x: 0xFF}
 
-    def subtract(w, minuend, sub_name, out_name, top_out=None):
+    def subtract(w, minuend, sub_name, out_name, top_out=None, clamp=True, out_reg=None):
         """out = max(0, minuend - sub) over B planes; minuend[i] = (kind, register name or None).  The top plane
-        comes out clamped (into `top_out` if given); the caller ANDs planes 0..B-2 with the returned mask."""
+        comes out clamped (into `top_out` if given); the caller ANDs planes 0..B-2 with the returned mask.
+        clamp = False: the caller knows minuend >= sub — plain difference, plane i into out_reg(i), no borrow out of the top plane."""
         carry = None
+        dst = (lambda i: out_reg(i)) if out_reg is not None else (lambda i: t(f"{out_name}{i}", w))
         for i in range(B):
             kind, name = minuend[i]
             f = lit[kind]
             src = name if name is not None else sub_name(i)
             if carry is None:      # bit 0: the +1 of the two's complement is the carry-in
                 if kind == "reg":
-                    b.XOR(t(f"{out_name}{i}", w), src, sub_name(i))
+                    b.XOR(dst(i), src, sub_name(i))
                 else:
-                    b.BITOP3(t(f"{out_name}{i}", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) ^ s)
-                carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) | ~s)
+                    b.BITOP3(dst(i), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) ^ s)
+                if B > 1 or clamp:
+                    carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), sub_name(i), lambda m, s, _s, f=f: f(m) | ~s)
+            elif i == B - 1 and not clamp:
+                b.BITOP3(dst(i), src, sub_name(i), carry, lambda m, s, cy, f=f: f(m) ^ ~s ^ cy)
+                carry = None
             elif i == B - 1:
                 # top plane: its clamp (difference bit AND "no borrow out of this plane") is a function of the same three
                 # inputs, so it costs no instruction of its own
@@ -1511,11 +1523,12 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
                 b.BITOP3(top_out or t(f"{out_name}{i}", w), src, sub_name(i), prev,
                          lambda m, s, cy, f=f, maj=maj: (f(m) ^ ~s ^ cy) & maj(m, s, cy))
             else:
-                b.BITOP3(t(f"{out_name}{i}", w), src, sub_name(i), carry, lambda m, s, cy, f=f: f(m) ^ ~s ^ cy)
+                b.BITOP3(dst(i), src, sub_name(i), carry, lambda m, s, cy, f=f: f(m) ^ ~s ^ cy)
                 carry = b.BITOP3(t(f"{out_name}c", w), src, sub_name(i), carry,
                                  lambda m, s, cy, f=f: (f(m) & ~s) | (f(m) & cy) | (~s & cy))
         return carry     # 1 = no borrow: the difference is >= 0; planes 0..B-2 still need their AND with it
 
+    w_of, ok_of = {}, {}    # word -> the planes of w as subtract() takes them; the "w >= u" mask of the first subtract
     for w in W:
         bx = _Bool(b, f"w{w}")
         cls_mask = {C - c: dv[c, w] for c in range(K)}
@@ -1563,11 +1576,26 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
             else:
                 wplanes.append((kind, bx.or_all(masks, "wp")))
         ok = subtract(w, wplanes, lambda i, w=w: U(w, i), "s")
+        w_of[w], ok_of[w] = wplanes, ok
         for i in range(B - 1 if B > 1 else B):
             b.AND(t(f"s{i}", w), t(f"s{i}", w), ok)
 
     # ---- max(W, u): C at a match, D at a mismatch with u <= D, else u -------------------------------
     def max_planes(w):
+        if BITPAL_CELL_MAX:
+            # The cell identity: with a = u, b = v_in and W the cell's substitution value, v = max(0, max(W, b) - a) and
+            # new u = max(0, max(W, a) - b) are m - a and m - b for m = max(W, a, b) — the largest of the three can be clamped by
+            # neither.  w = max(W, b) is in hand (the class masks), "w >= u" is the first subtract's borrow: m = w or u by that
+            # mask, one instruction per plane (what max(W, u) cost), and the second subtract needs no clamp and no borrow out of
+            # its top plane: four instructions per word fewer (2/-3/-5: 68 -> 64), and the "u <= D" comparator has no reader left.
+            for i in range(B):
+                kind, name = w_of[w][i]
+                f = lit[kind]
+                if name is None:
+                    b.BITOP3(t(f"g{i}", w), U(w, i), ok_of[w], ok_of[w], lambda u, ok, _ok, f=f: (f(0) & ok) | (u & ~ok))
+                else:
+                    b.BITOP3(t(f"g{i}", w), name, U(w, i), ok_of[w], lambda wp, u, ok, f=f: (f(wp) & ok) | (u & ~ok))
+            return
         for i in range(B):
             cb, db = 0xFF * ((C >> i) & 1), 0xFF * ((D >> i) & 1)
             if w in le_plane:      # "u <= D" is the complement of one plane: read it directly (one instruction per word saved)
@@ -1590,6 +1618,10 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
 
     # ---- new u = max(0, max(W, u) - v_in) -------------------------------------------------------------
     for w in W:
+        if BITPAL_CELL_MAX:
+            subtract(w, [("reg", t(f"g{i}", w)) for i in range(B)], lambda i, w=w: t(f"s{i}", w), "r", clamp=False,
+                     out_reg=lambda i, w=w: U(w, i))
+            continue
         ok = subtract(w, [("reg", t(f"g{i}", w)) for i in range(B)], lambda i, w=w: t(f"s{i}", w), "r",
                       top_out=U(w, B - 1) if B > 1 else None)
         for i in range(B - 1 if B > 1 else B):
