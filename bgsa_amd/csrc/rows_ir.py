@@ -1318,6 +1318,9 @@ BITPAL_INLINE_LE = __import__('os').environ.get('BGSA_GEN_BITPAL_INLINE_LE', '1'
 # round 4, second step: new u = max(w, u) - v_in needs no clamp (see bitpal_scores_body: "the cell identity"); '0' builds the
 # previous form, new u = max(0, max(W, u) - v_in), for A/B
 BITPAL_CELL_MAX = __import__('os').environ.get('BGSA_GEN_BITPAL_CELL_MAX', '1') != '0'
+# the one-hot mask of u = K - 1 has ONE reader — the lowest class's seed term with the top class — so that product is formed from the
+# planes and the class mask directly: one instruction per word fewer ('0': the mask is built like the others, for A/B)
+BITPAL_FOLD_LAST_Z = __import__('os').environ.get('BGSA_GEN_BITPAL_FOLD_LAST_Z', '1') != '0'
 
 
 
@@ -1387,7 +1390,17 @@ class _Bool:
 
 @__import__("functools").lru_cache(maxsize=256)
 def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
-    """(Memoised: callers treat the returned Body as read-only.)  Row body for `nw` words.  State S[w*B + i] = plane i (weight 2^i) of the UNSIGNED value u of word
+    """(Memoised: callers treat the returned Body as read-only.)  The row body for `nw` words, with the single-use one-hot mask folded into
+    its seed product where that saves an instruction for this score set (it does when the mask shares no partial product with the others:
+    2/-3/-5 64 -> 63; 10/-9/-15 would lose one)."""
+    if BITPAL_FOLD_LAST_Z and _bitpal_scores_body(1, sc, True).valu_count() < _bitpal_scores_body(1, sc, False).valu_count():
+        return _bitpal_scores_body(nw, sc, True)
+    return _bitpal_scores_body(nw, sc, False)
+
+
+@__import__("functools").lru_cache(maxsize=512)
+def _bitpal_scores_body(nw: int, sc: BitpalScores, fold_last_z: bool) -> Body:
+    """Row body for `nw` words.  State S[w*B + i] = plane i (weight 2^i) of the UNSIGNED value u of word
     w's 32 columns, B = sc.planes = bits(C) (the reference keeps the two's complement of -u in one more
     plane, align_core.c:191-214; the unsigned form saves that plane and four instructions per word).
     E[w] = match mask.  Chains (in order): the top-class run, then per lower class the seed shift and its run (one chain
@@ -1419,6 +1432,8 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
             low = bx.or_all(planes[:B - 2], "lo") if B > 3 else planes[0]
             z0 = bx.op3(lambda a, b_, c: ~(a | b_ | c), low, planes[B - 2], planes[B - 1], "z0")   # u == 0
         for x in range(1, K):
+            if fold_last_z and x == K - 1 and K > 2 and B > 1:
+                continue      # read once, by seed K-1's first term: folded into that product below
             z[x, w] = bx.and_pattern(msb_first, [(x >> i) & 1 for i in range(B - 1, -1, -1)]) if B > 1 else planes[0]
         # u <= D: constant comparator from the LSB up (r = "the bits seen so far are <= the constant's";
         # a one bit of D ORs the complemented plane in, a zero bit ANDs it)
@@ -1486,7 +1501,13 @@ def bitpal_scores_body(nw: int, sc: BitpalScores = BITPAL_DEFAULT) -> Body:
     # ---- classes C-1 .. D+1: value C-c appears where an incoming class C-x meets u = c-x ----------
     for c in range(1, K):
         for w in W:
-            b.AND(t(f"seed{c}", w), z[c, w], dv[0, w])
+            if (c, w) not in z:      # fold_last_z: [u = K - 1] AND the top class in one product over the planes and the mask
+                msb_first = [U(w, i) for i in range(B)][::-1]
+                first = _Bool(b, f"q{w}").and_pattern(msb_first + [dv[0, w]], [(c >> i) & 1 for i in range(B - 1, -1, -1)] + [1], "zs")
+                b.ops[-1].dst = t(f"seed{c}", w)
+                assert first != t(f"seed{c}", w)
+            else:
+                b.AND(t(f"seed{c}", w), z[c, w], dv[0, w])
             for x in range(1, c):
                 b.BITOP3(t(f"seed{c}", w), z[c - x, w], dv[x, w], t(f"seed{c}", w), lambda a, b_, acc: (a & b_) | acc)
         shifted_run(f"seed{c}", c)

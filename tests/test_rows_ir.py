@@ -324,12 +324,13 @@ def test_bitpal_any_scores_column_blocks(oracle, scores, qlen, slen, nwb):
 
 def test_bitpal_default_scores_instance():
     # 2/-3/-5: u in 0..12 on four unsigned planes (the reference keeps -u in five, align_core.c:191-214),
-    # five value classes above the mismatch class, thirteen carry chains, 64 instructions per word (69 in round 3, 68 with
-    # "u <= 7" read off plane 3; then the cell identity: new u = max(w, u) - v_in needs no clamp and no "u <= 7" at all)
+    # five value classes above the mismatch class, thirteen carry chains, 63 instructions per word (69 in round 3, 68 with
+    # "u <= 7" read off plane 3; 64 with the cell identity: new u = max(w, u) - v_in needs no clamp and no "u <= 7" at all;
+    # 63 with the single-use mask of u = 4 folded into its seed product)
     sc = R.BITPAL_DEFAULT
     assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (4, 13, 12, 7, 5)
     assert sc.weights() == (1, 2, 4, 8)
-    assert R.bitpal_body(1).valu_count() == 64
+    assert R.bitpal_body(1).valu_count() == 63
 
 
 def test_bitpal_edit_scores_equal_negated_myers(oracle):
