@@ -357,7 +357,46 @@ def schedule(body: "Body", window: int = 48) -> "Body":
 # Myers unit-cost global (reference original/BGSA_CPU/align_core.c:65-132)
 # =================================================================================================
 
+MYERS_EIGHT = __import__('os').environ.get('BGSA_GEN_MYERS_EIGHT', '1') != '0'   # '0': the 10-instruction rows of rounds 1-3 (A/B builds)
+
+
 def myers_body(nw: int, groups: int = 1) -> Body:
+    """State layout: S[(g*nw + w)*2 + 0] = VP word w of group g, +1 = VN.  E[g*nw + w] = match mask.
+
+    Per word EIGHT instructions and two carry chains (round 4; ten and three until then: myers_body10).  In the terms of the
+    general-scores body (u = 1 - dH in {0, 1, 2}: VP = [u = 0], VN = [u = 2]; v = 1 - dV likewise) a cell is m = max(W, u, v_in),
+    v = m - u, new u = m - v_in with W = 2 at a match, 1 otherwise — so m is ONE bit, M2 = [m = 2] = E | VN | [v_in = 2], and
+    [v_in = 2] of column j + 1 is VP_j & M2_j = (VP_j & E_j) | (VP_j & [v_in = 2]_j): a carry with generate VP & E and propagate
+    VP, i.e. the carries of the addition VP + (VP & E), and the carry INTO a bit is sum ^ VP ^ (VP & E) — [v_in = 2] comes out of
+    the adder already moved up one column, across the words.  What the classical order pays for (HN and its shift) is gone:
+        a = VP & E ; s = VP + a (chain, carry-in 0) ; HNs = s ^ VP ^ a ; M2 = E | VN | HNs ; HP = VN | ~(M2 | VP)
+        HPs = HP << 1 (chain, carry-in 1: the row edge) ; VN' = M2 & HPs ; VP' = (M2 & HNs) | ~(M2 | HPs)
+    (reference: 24 ops per 31-bit word, align_core.c:72-103).  Two temporaries per word: HP is formed in the dead VP register."""
+    if not MYERS_EIGHT:
+        return myers_body10(nw, groups)
+    b = Body()
+    for g in range(groups):
+        VP = lambda w: f"S{(g * nw + w) * 2}"
+        VN = lambda w: f"S{(g * nw + w) * 2 + 1}"
+        E = lambda w: f"E{g * nw + w}"
+        A = lambda w: f"a{g}_{w}"      # VP & E, then [v_in = 2]
+        M = lambda w: f"m{g}_{w}"      # the sum, then M2
+        for w in range(nw):  # phase A: the addition's carry chain
+            b.AND(A(w), VP(w), E(w))
+            (b.ADD_CO if w == 0 else b.ADDC)(M(w), VP(w), A(w))
+            if w == nw - 1:
+                b.SETC1()    # the row edge D[i][0] - D[i-1][0] = +1 enters HP at bit 0 of word 0; three instructions ahead of its reader
+            b.BITOP3(A(w), M(w), VP(w), A(w), lambda s_, vp, a: s_ ^ vp ^ a)
+            b.BITOP3(M(w), E(w), VN(w), A(w), lambda e, vn, hn: e | vn | hn)
+            b.BITOP3(VP(w), M(w), VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+        for w in range(nw):  # phase B: HP << 1 across words, then the new deltas
+            b.ADDC(VP(w), VP(w), VP(w))
+            b.AND(VN(w), M(w), VP(w))
+            b.BITOP3(VP(w), M(w), A(w), VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+    return b
+
+
+def myers_body10(nw: int, groups: int = 1) -> Body:
     """State layout: S[(g*nw + w)*2 + 0] = VP word w of group g, +1 = VN.  E[g*nw + w] = match mask.
 
     Per word (10 instructions, full 32-bit words, hardware carries instead of the reference's
@@ -393,7 +432,10 @@ def myers_body(nw: int, groups: int = 1) -> Body:
 def myers_parked_body(nw: int) -> Body:
     """myers_body for 26..28 words: HN is parked in the VP register between the phases (as myers_planes_body does), so
     a word needs 9 registers instead of 10 — 5 Peq masks, VP, VN, D0, HP — and 28 words (896 bp) still fit 256 VGPRs
-    with two waves per SIMD.  Same 10 instructions per word; state and masks as myers_body (one group)."""
+    with two waves per SIMD.  Same 10 instructions per word; state and masks as myers_body (one group).
+    (Round 4's eight-instruction myers_body needs nine registers per word as it is — HP lives in the dead VP register — and replaces it.)"""
+    if MYERS_EIGHT:
+        return myers_body(nw, 1)
     b = Body()
     P = lambda w: f"S{w * 2}"
     M = lambda w: f"S{w * 2 + 1}"
@@ -631,7 +673,7 @@ def myers_peq_block_body(nw: int) -> Body:
     """Column-block form of myers_body (Peq planes resident, 10 VALU per word + 6 for the carry words),
     derived mechanically like the BitPAl block bodies.  Chains: addition (carry-in 0), HP shift (carry-in
     1 in the first block: the row edge), HN shift (0)."""
-    body, init = make_blocked(myers_body(nw, 1), 2 * nw)
+    body, init = make_blocked(myers_body10(nw, 1), 2 * nw)      # (the column blocks keep the three-chain rows: their kernels carry three words)
     assert init == [0, 1, 0]
     return schedule(body, 16)
 

@@ -57,7 +57,7 @@ def test_myers_parked_body_matches_oracle(oracle, qlen, slen, nw):
         st = R.myers_init_state(nw, 1, s.shape[0])
         R.run_rows(body, st, peq, q[i])
         assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
-    assert body.valu_count() == 10 * nw and R.count_hazard_nops(body) == 0 and body.allocate_temps()[1] == 2 * nw
+    assert body.valu_count() == 8 * nw and R.count_hazard_nops(body) == 0 and body.allocate_temps()[1] == 2 * nw
 
 
 @pytest.mark.parametrize("qlen,slen,nw", [(200, 60, 2), (150, 150, 5), (33, 97, 4), (1, 1, 1), (120, 64, 2), (300, 250, 8),
