@@ -470,6 +470,29 @@ def myers_semi_body(nw: int) -> Body:
         score with one add-with-carry each, plus one v_min for the best score — 3 instructions per row on top of
         the 10 per word, nothing extracted bit by bit.
     State: myers_body's, then S[2nw] = D[i][n] (running), S[2nw+1] = its minimum so far."""
+    if MYERS_EIGHT:
+        # the eight-instruction row (myers_body): the carry that LEAVES the addition chain is [v = 2] of the last column = its HN bit,
+        # the one that leaves the HP shift its HP bit — the same two score updates, 8 VALU per word + 3 per row
+        b = Body()
+        VP = lambda w: f"S{w * 2}"
+        VN = lambda w: f"S{w * 2 + 1}"
+        RUN, BEST = f"S{2 * nw}", f"S{2 * nw + 1}"
+        for w in range(nw):
+            b.AND(f"a{w}", VP(w), f"E{w}")
+            (b.ADD_CO if w == 0 else b.ADDC)(f"m{w}", VP(w), f"a{w}")
+            b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
+            b.BITOP3(f"m{w}", f"E{w}", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
+            if w == nw - 1:
+                b.SUBBZ(RUN)                    # - the HN bit that left the last column (two instructions behind the chain's last link)
+            b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+        for w in range(nw):  # HP << 1 across words, carry-in 0
+            (b.ADD_CO if w == 0 else b.ADDC)(VP(w), VP(w), VP(w))
+            b.AND(VN(w), f"m{w}", VP(w))
+            if w == nw - 1:
+                b.ADDCZ(RUN)                    # + the HP bit that left the last column (before anything else writes VCC)
+            b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        b.MINU(BEST, BEST, RUN)
+        return b
     b = Body()
     P = lambda w: f"S{w * 2}"
     M = lambda w: f"S{w * 2 + 1}"
@@ -546,6 +569,24 @@ def myers_planes_body(nw: int) -> Body:
     of the row's class is rebuilt per word with one v_bitop3 (MATCH3) — 11 instructions per word,
     7*nw+1 registers, which keeps 32 words (1024 bp) at two waves per SIMD.  State as myers_body.
     """
+    if MYERS_EIGHT:      # myers_body's eight instructions + the match mask: 9 per word, the same 7*nw + 1 registers
+        b = Body()
+        VP = lambda w: f"S{w * 2}"
+        VN = lambda w: f"S{w * 2 + 1}"
+        for w in range(nw):
+            b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}")
+            b.AND(f"a{w}", VP(w), "e")
+            (b.ADD_CO if w == 0 else b.ADDC)(f"m{w}", VP(w), f"a{w}")
+            if w == nw - 1:
+                b.SETC1()
+            b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
+            b.BITOP3(f"m{w}", "e", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
+            b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+        for w in range(nw):
+            b.ADDC(VP(w), VP(w), VP(w))
+            b.AND(VN(w), f"m{w}", VP(w))
+            b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        return b
     b = Body()
     P = lambda w: f"S{w * 2}"
     M = lambda w: f"S{w * 2 + 1}"
@@ -576,6 +617,28 @@ def myers_semi_planes_body(nw: int) -> Body:
     last-column score — and the unused low columns coded 7 in the planes, the code that matches every class (MATCH3
     wild), so they cost no instruction.  11 VALU per word + 3 per row.
     State: S[2w] = VP, S[2w+1] = VN, S[2nw] = D[i][n], S[2nw+1] = its minimum so far."""
+    if MYERS_EIGHT:      # as myers_semi_body's eight-instruction form, the match mask from the code planes: 9 per word + 3 per row
+        b = Body()
+        VP = lambda w: f"S{w * 2}"
+        VN = lambda w: f"S{w * 2 + 1}"
+        RUN, BEST = f"S{2 * nw}", f"S{2 * nw + 1}"
+        for w in range(nw):
+            b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}", wild=True)
+            b.AND(f"a{w}", VP(w), "e")
+            (b.ADD_CO if w == 0 else b.ADDC)(f"m{w}", VP(w), f"a{w}")
+            b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
+            b.BITOP3(f"m{w}", "e", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
+            if w == nw - 1:
+                b.SUBBZ(RUN)
+            b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+        for w in range(nw):
+            (b.ADD_CO if w == 0 else b.ADDC)(VP(w), VP(w), VP(w))
+            b.AND(VN(w), f"m{w}", VP(w))
+            if w == nw - 1:
+                b.ADDCZ(RUN)
+            b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        b.MINU(BEST, BEST, RUN)
+        return b
     b = Body()
     P = lambda w: f"S{w * 2}"
     M = lambda w: f"S{w * 2 + 1}"
@@ -639,6 +702,29 @@ def myers_block_body(nw: int) -> Body:
     first row in bit 31:  x + x  shifts the next row's carry-in into VCC,  x + x + vcc  appends
     the row's carry-out — six extra fast-class instructions per row, no bit extraction.
     State: S[2w] = VP, S[2w+1] = VN, then CIN_S, CIN_P, CIN_N, COUT_S, COUT_P, COUT_N."""
+    if MYERS_EIGHT:      # two chains: the addition (its carries are [v_in = 2]) and the HP shift; the third pair of carry words stays unused
+        b = Body()
+        VP = lambda w: f"S{w * 2}"
+        VN = lambda w: f"S{w * 2 + 1}"
+        CIN = [f"S{2 * nw + i}" for i in range(3)]
+        COUT = [f"S{2 * nw + 3 + i}" for i in range(3)]
+        b.ADD_CO(CIN[0], CIN[0], CIN[0])
+        for w in range(nw):
+            b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}")
+            b.AND(f"a{w}", VP(w), "e")
+            b.ADDC(f"m{w}", VP(w), f"a{w}")
+            if w == nw - 1:
+                b.ADDC(COUT[0], COUT[0], COUT[0])
+                b.ADD_CO(CIN[1], CIN[1], CIN[1])
+            b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
+            b.BITOP3(f"m{w}", "e", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
+            b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+        for w in range(nw):
+            b.ADDC(VP(w), VP(w), VP(w))
+            b.AND(VN(w), f"m{w}", VP(w))
+            b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        b.ADDC(COUT[1], COUT[1], COUT[1])
+        return schedule(b, 16)
     b = Body()
     P = lambda w: f"S{w * 2}"
     M = lambda w: f"S{w * 2 + 1}"
@@ -670,10 +756,14 @@ def myers_block_body(nw: int) -> Body:
 
 
 def myers_peq_block_body(nw: int) -> Body:
-    """Column-block form of myers_body (Peq planes resident, 10 VALU per word + 6 for the carry words),
+    """Column-block form of myers_body (Peq planes resident, 8 VALU per word + 4 for the carry words; 10 + 6 until round 4),
     derived mechanically like the BitPAl block bodies.  Chains: addition (carry-in 0), HP shift (carry-in
     1 in the first block: the row edge), HN shift (0)."""
-    body, init = make_blocked(myers_body10(nw, 1), 2 * nw)      # (the column blocks keep the three-chain rows: their kernels carry three words)
+    if MYERS_EIGHT:      # two chains in the first two of the kernel's three carry-word pairs (the second starts with the row edge, as before)
+        body, init = make_blocked(myers_body(nw, 1), 2 * nw, n_slots=3)
+        assert init == [0, 1]
+        return schedule(body, 16)
+    body, init = make_blocked(myers_body10(nw, 1), 2 * nw)
     assert init == [0, 1, 0]
     return schedule(body, 16)
 
@@ -1730,7 +1820,7 @@ def bitpal_scores_score(state: list, nw: int, qlen: int, slen: int, sc: BitpalSc
     return score.astype(np.int16)
 
 
-def make_blocked(body: Body, n_state: int):
+def make_blocked(body: Body, n_state: int, n_slots: int | None = None):
     """Column-block form of a row body: every carry chain enters and leaves through a carry word
     (32 rows per word, first row in bit 31).  Chain k reads its carry-in with `x + x` on state
     register S[n_state + k] (VCC = next row's bit) and appends its carry-out with `x + x + vcc` on
@@ -1743,7 +1833,8 @@ def make_blocked(body: Body, n_state: int):
             chains.append((i, 0))
         elif op.kind == "setc1":
             chains.append((i, 1))
-    n = len(chains)
+    n = len(chains) if n_slots is None else n_slots      # n_slots: the kernel's carry-word pairs when it has more than the body has chains
+    assert len(chains) <= n
     starts = {i: k for k, (i, _) in enumerate(chains)}
     out = Body()
     open_chain = None
