@@ -149,7 +149,7 @@ struct Plan {
 //     mismatch < 2*gap is the mismatch = 2*gap instance;
 //   * scores with a common factor f run as the reduced set and the result is multiplied by f;
 //   * the reduced set 0/-1/-1 in global mode is minus the edit distance: it runs on the Myers body
-//     (10 VALU per word against 22 for the BitPAl body of that set) — the reference's `isEdit`
+//     (8 VALU per word against 17 for the BitPAl body of that set) — the reference's `isEdit`
 //     specialisation (Main.java:270-271) taken to its conclusion.
 static int make_plan(const bgsa_hip_params_t &p, Plan *plan)
 {

@@ -32,7 +32,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 import rows_ir as R  # noqa: E402
 
-MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25]  # Peq masks resident: 10 VALU per word (25 words = 253 VGPRs, the last width with two waves per SIMD)
+MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25]  # Peq masks resident: 8 VALU per word (25 words = 253 VGPRs, the last width with two waves per SIMD)
 # resident Peq masks with 9 registers per word (rows_ir.myers_parked_body): 26 and 28 words (801..896 bp) fit 256 VGPRs at all,
 # 18 words (545..576 bp) drop from 183 to 165 VGPRs = three waves per SIMD instead of two
 MYERS_PARKED_NW = [18, 26, 28]
@@ -1475,7 +1475,7 @@ def main() -> int:
         for g in (1, 2):
             parts.append(gen_pair_function("myers_pair_rows_asm", f"{nw}, {g}", R.myers_body(nw, g), 2 * g * nw, g * nw))
     parts.append("\n// Semi-global (generator -m 0 -s): rows_ir.py: myers_semi_body — the subject right-aligned in its NW words,\n"
-                 "// state = {VP, VN} x NW, then D[i][n] (running) and its minimum; 10 VALU per word + 3 per row.\n"
+                 "// state = {VP, VN} x NW, then D[i][n] (running) and its minimum; 8 VALU per word + 3 per row.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ int myers_semi_rows_asm(uint32_t (&state)[2 * NW + 2],\n"
                  "                                                   const uint32_t (&P)[5][NW],\n"
@@ -1490,7 +1490,7 @@ def main() -> int:
     for nw in MYERS_PLANES_NW:
         parts.append(gen_function("myers_planes_rows_asm", f"{nw}", R.myers_planes_body(nw), 2 * nw, 0, n_planes=3 * nw))
     parts.append("\n// Semi-global on the code planes (subjects of 769..1024 bp): rows_ir.py: myers_semi_planes_body — the unused low\n"
-                 "// columns carry code 7, which matches every class; 11 VALU per word + 3 per row.\n"
+                 "// columns carry code 7, which matches every class; 9 VALU per word + 3 per row.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ int myers_semi_planes_rows_asm(uint32_t (&state)[2 * NW + 2],\n"
                  "                                                           const uint32_t (&B)[3 * NW],\n"
@@ -1507,7 +1507,7 @@ def main() -> int:
                  "                                                     const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_BLOCK_NW:
         parts.append(gen_blocked_function("myers_block_rows_asm", nw, R.myers_block_body(nw), 2 * nw, 3, 3 * nw, 0))
-    parts.append("\n// The same with the five Peq planes of the block resident instead of the code planes: 10 VALU per word,\n"
+    parts.append("\n// The same with the five Peq planes of the block resident instead of the code planes: 8 VALU per word,\n"
                  "// narrower blocks (rows_ir.py: myers_peq_block_body).\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ int myers_peq_block_rows_asm(uint32_t (&state)[2 * NW + 6], const uint32_t (&P)[5][NW],\n"

@@ -12,15 +12,15 @@
 //     one of five copies of the row body by a scalar jump, so `Eq = Peq[c][w]` costs no VALU
 //     work (the reference pays a pointer add + a vector load per word, align_core.c:67,74).
 //   * Words are full 32-bit (the reference keeps bit W-1 free as a software carry,
-//     align_core.c:79-83,91-96): the addition and both 1-bit shifts are add-with-carry chains
-//     through VCC.
+//     align_core.c:79-83,91-96): the addition and the 1-bit shift of HP are add-with-carry chains
+//     through VCC; HN needs no shift — it is read off the addition's carries (rows_ir.py: myers_body).
 //   * The score is not tracked per row (align_core.c:121-124); after the last row
 //     D[m][n] = m + popcount(VP & mask) - popcount(VN & mask), two v_bcnt per word.
 //
 // Three kernels, chosen by launch_myers():
-//   myers_global_asm_kernel<NW,1>   1..768 bp    generated asm row loop, Peq planes resident, 10 VALU per (row, word)
+//   myers_global_asm_kernel<NW,1>   1..768 bp    generated asm row loop, Peq planes resident, 8 VALU per (row, word)
 //   myers_global_planes_kernel<NW>  769..1024 bp generated asm row loop on 3-bit character-code
-//                                                planes, 11 VALU per (row, word)
+//                                                planes, 9 VALU per (row, word)
 //   myers_global_kernel<NW,1>       compiler-scheduled C++ of the same recurrence: the A/B
 //                                   reference for the asm (BGSA_MYERS_IMPL=c), 124 vs 216 TCUPS
 //   myers_blocked_kernel<NW>        > 1024 bp    column blocks of the planes body, carries between
@@ -280,7 +280,7 @@ __device__ __forceinline__ uint32_t semi_dummy_mask(int aw, int s)
 }
 
 // Subjects up to 768 bp (the widths with resident Peq planes): generated asm row loop of myers_semi_body,
-// 10 VALU per word + 3 per row.
+// 8 VALU per word + 3 per row.
 template <int NW>
 __global__ __launch_bounds__(256) void myers_semi_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void myers_semi_asm_kernel(
 
 // Long subjects (769..1024 bp; 257..1024 before the Peq-resident kernels were widened): the wave turns its five Peq planes into the subject's 3-bit
 // character-code planes once per task (B0 = C|T, B1 = G|T, B2 = N) and the row body rebuilds the
-// match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 11 VALU per
+// match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 9 VALU per
 // word, 7*NW+1 registers, two waves per SIMD at NW = 32.
 template <int NW, bool DYN = false>
 __global__ __launch_bounds__(256) void myers_global_planes_kernel(
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void myers_global_planes_kernel(
 
 // Semi-global for subjects of 769..1024 bp: the code planes right-aligned like the Peq planes of myers_semi_asm_kernel;
 // the unused low columns get code 7 (all three planes set), which MATCH3's truth tables treat as "matches every
-// class" (rows_ir.py: myers_semi_planes_body) — 11 VALU per word + 3 per row, two waves per SIMD at NW = 32.
+// class" (rows_ir.py: myers_semi_planes_body) — 9 VALU per word + 3 per row, two waves per SIMD at NW = 32.
 template <int NW>
 __global__ __launch_bounds__(256) void myers_semi_planes_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
             int score = ref_len;
             for (int blk = 0; blk < n_blocks; blk++) {
                 uint32_t Bp[PEQ ? 1 : 3 * NW];       // 3-bit character-code planes of the block, or
-                uint32_t Pq[kChars][PEQ ? NW : 1];   // its five Peq planes (PEQ: 10 VALU per word, narrower blocks)
+                uint32_t Pq[kChars][PEQ ? NW : 1];   // its five Peq planes (PEQ: 8 VALU per word, narrower blocks)
                 if constexpr (SEMI) {
 #pragma unroll
                     for (int c = 0; c < kChars; c++) {
@@ -862,7 +862,7 @@ int myers_max_plain_words()
     return limit;
 }
 
-// Widest subject (words) that keeps its five Peq planes in registers (10 VALU per word); wider ones use
+// Widest subject (words) that keeps its five Peq planes in registers (8 VALU per word); wider ones use
 // the 3-bit code planes (11 per word, fewer registers).  BGSA_MYERS_PEQ_MAX_WORDS overrides (measurement).
 int myers_peq_max_words()
 {
