@@ -1515,6 +1515,9 @@ def main() -> int:
                  "                                                         const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PEQ_BLOCK_NW:
         parts.append(gen_blocked_function("myers_peq_block_rows_asm", nw, R.myers_peq_block_body(nw), 2 * nw, 3, 0, nw))
+    parts.append("\n// Which of a block row's three carry-word pairs holds the HN bit that leaves the block's last column (pair 1 holds the HP bit):\n"
+                 "// the eight-instruction row reads HN off the ADDITION's carries (pair 0), the ten-instruction row shifted it in a chain of its own (pair 2).\n"
+                 f"constexpr int kMyersBlockHnPair = {0 if R.MYERS_EIGHT else 2};\n")
     (here / "myers_rows_gen.inc").write_text("".join(parts))
     # ---- BitPAl, default scores (other score sets: gen_bitpal_sets.py) ------------------------
     (here / "bitpal_rows_gen.inc").write_text(bitpal_inc_text(R.BITPAL_DEFAULT))

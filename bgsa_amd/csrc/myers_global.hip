@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void myers_blocked_kernel(
                 // column n, first row in bit 31 — D[i][n] - D[i-1][n] row by row.  D[0][n] = n.
                 int run = read_len, best = read_len;
                 for (int c = 0; c < n_chunks; c++) {
-                    const uint32_t hpw = carry[(c * 3 + 1) * kLanes + lane], hnw = carry[(c * 3 + 2) * kLanes + lane];
+                    const uint32_t hpw = carry[(c * 3 + 1) * kLanes + lane], hnw = carry[(c * 3 + kMyersBlockHnPair) * kLanes + lane];
                     const int rows = ref_len - 32 * c < 32 ? ref_len - 32 * c : 32;
                     for (int b2 = 0; b2 < rows; b2++) {
                         run += static_cast<int>((hpw >> (31 - b2)) & 1u) - static_cast<int>((hnw >> (31 - b2)) & 1u);
