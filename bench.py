@@ -105,7 +105,7 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
         return None
     if algo == B.ALGO_MYERS and wn <= 28:      # Peq planes resident (myers_global_asm_kernel): 8 VALU per word at every width
         nw = wn if wn <= 8 or wn == 25 else next(n for n in list(range(10, 25, 2)) + [26, 28] if n >= wn)
-        return 10 * nw
+        return R.myers_body(nw).valu_count()
     if algo == B.ALGO_MYERS and wn <= 32:      # 3-bit code planes (myers_global_planes_kernel)
         nw = next(n for n in range(26, 33, 2) if n >= wn)
         return R.myers_planes_body(nw).valu_count()
