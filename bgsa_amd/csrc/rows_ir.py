@@ -1635,9 +1635,8 @@ def _bitpal_scores_body(nw: int, sc: BitpalScores, fold_last_z: bool) -> Body:
         for w in W:
             if (c, w) not in z:      # fold_last_z: [u = K - 1] AND the top class in one product over the planes and the mask
                 msb_first = [U(w, i) for i in range(B)][::-1]
-                first = _Bool(b, f"q{w}").and_pattern(msb_first + [dv[0, w]], [(c >> i) & 1 for i in range(B - 1, -1, -1)] + [1], "zs")
-                b.ops[-1].dst = t(f"seed{c}", w)
-                assert first != t(f"seed{c}", w)
+                _Bool(b, f"q{w}").and_pattern(msb_first + [dv[0, w]], [(c >> i) & 1 for i in range(B - 1, -1, -1)] + [1], "zs")
+                b.ops[-1].dst = t(f"seed{c}", w)      # the product's last instruction IS the seed's first term: name it so
             else:
                 b.AND(t(f"seed{c}", w), z[c, w], dv[0, w])
             for x in range(1, c):
