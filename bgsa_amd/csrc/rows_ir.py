@@ -1453,6 +1453,10 @@ BITPAL_CELL_MAX = __import__('os').environ.get('BGSA_GEN_BITPAL_CELL_MAX', '1') 
 # the one-hot mask of u = K - 1 has ONE reader — the lowest class's seed term with the top class — so that product is formed from the
 # planes and the class mask directly: one instruction per word fewer ('0': the mask is built like the others, for A/B)
 BITPAL_FOLD_LAST_Z = __import__('os').environ.get('BGSA_GEN_BITPAL_FOLD_LAST_Z', '1') != '0'
+# the run mask (u = 0 at a MISMATCH) is not needed: the classes may propagate through every u = 0 column — what runs through a u = 0
+# match column is covered, column by column, by the top class's own propagation from that very column, and the extraction masks
+# with the top class instead of the match mask.  One instruction per word fewer ('0': the run mask, for A/B).
+BITPAL_NO_RUN = __import__('os').environ.get('BGSA_GEN_BITPAL_NO_RUN', '1') != '0'
 
 
 
@@ -1547,6 +1551,7 @@ def _bitpal_scores_body(nw: int, sc: BitpalScores, fold_last_z: bool) -> Body:
     anym = {}   # word -> mismatch columns whose u <= D
     le_plane = {}   # word -> the ONE plane p with "u <= D  <=>  ~p" (D + 1 a power of two): no mask of its own is built
     dv = {}     # (class offset c, word) -> columns whose incoming v is C - c (c = 0: or a match)
+    prop, stop = {}, {}   # word -> the columns a class value runs through unchanged; the columns that end up in the top class whatever arrives
 
     # ---- decode the u classes the seeds need, the "u <= D" mask, and the top-class run ----------
     for w in W:
@@ -1608,7 +1613,14 @@ def _bitpal_scores_body(nw: int, sc: BitpalScores, fold_last_z: bool) -> Body:
             else:
                 anym[w] = bx.op3(lambda le, e, _e: le & ~e, cur, E(w), E(w), "any")
         b.AND(t("seed", w), z0, E(w))
+        if BITPAL_NO_RUN:
+            prop[w] = z0
+            (b.ADD_CO if w == 0 else b.ADDC)(t("sum", w), t("seed", w), z0)
+            dv[0, w] = b.BITOP3(t("dvtop", w), t("sum", w), z0, E(w), lambda s, z_, e: (s ^ (z_ & ~e)) | e)
+            stop[w] = dv[0, w]
+            continue
         b.XOR(t("run", w), z0, t("seed", w))                       # u == 0 at a mismatch
+        prop[w], stop[w] = t("run", w), E(w)
         (b.ADD_CO if w == 0 else b.ADDC)(t("sum", w), t("seed", w), z0)
         dv[0, w] = b.BITOP3(t("dvtop", w), t("sum", w), t("run", w), E(w), lambda s, r, e: (s ^ r) | e)
 
@@ -1621,14 +1633,14 @@ def _bitpal_scores_body(nw: int, sc: BitpalScores, fold_last_z: bool) -> Body:
             for w in W:
                 (b.ADD_CO if w == 0 else b.ADDC)(t(seed_name, w), t(seed_name, w), t(seed_name, w))
             for w in W:
-                (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(seed_name, w), t("run", w))
-                dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
+                (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(seed_name, w), prop[w])
+                dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), prop[w], stop[w], lambda s, r, e: (s ^ r) & ~e)
             return
         for w in W:
-            b.OR(t(f"sr{c}", w), t(seed_name, w), t("run", w))
+            b.OR(t(f"sr{c}", w), t(seed_name, w), prop[w])
         for w in W:
             (b.ADD_CO if w == 0 else b.ADDC)(t(f"rs{c}", w), t(f"sr{c}", w), t(seed_name, w))
-            dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), t("run", w), E(w), lambda s, r, e: (s ^ r) & ~e)
+            dv[c, w] = b.BITOP3(t(f"dv{c}", w), t(f"rs{c}", w), prop[w], stop[w], lambda s, r, e: (s ^ r) & ~e)
 
     # ---- classes C-1 .. D+1: value C-c appears where an incoming class C-x meets u = c-x ----------
     for c in range(1, K):

@@ -335,7 +335,7 @@ def test_bitpal_default_scores_instance():
     sc = R.BITPAL_DEFAULT
     assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (4, 13, 12, 7, 5)
     assert sc.weights() == (1, 2, 4, 8)
-    assert R.bitpal_body(1).valu_count() == 63
+    assert R.bitpal_body(1).valu_count() == 62
 
 
 def test_bitpal_edit_scores_equal_negated_myers(oracle):
