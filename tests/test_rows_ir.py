@@ -329,9 +329,10 @@ def test_bitpal_any_scores_column_blocks(oracle, scores, qlen, slen, nwb):
 
 def test_bitpal_default_scores_instance():
     # 2/-3/-5: u in 0..12 on four unsigned planes (the reference keeps -u in five, align_core.c:191-214),
-    # five value classes above the mismatch class, thirteen carry chains, 63 instructions per word (69 in round 3, 68 with
+    # five value classes above the mismatch class, thirteen carry chains, 62 instructions per word (69 in round 3, 68 with
     # "u <= 7" read off plane 3; 64 with the cell identity: new u = max(w, u) - v_in needs no clamp and no "u <= 7" at all;
-    # 63 with the single-use mask of u = 4 folded into its seed product)
+    # 63 with the single-use mask of u = 4 folded into its seed product; 62 without the run mask: the classes propagate through
+    # every u = 0 column and the extraction masks with the top class)
     sc = R.BITPAL_DEFAULT
     assert (sc.planes, sc.chains, sc.C, sc.D, sc.K) == (4, 13, 12, 7, 5)
     assert sc.weights() == (1, 2, 4, 8)
