@@ -509,3 +509,26 @@ def test_banded_pair_row_with_one_64_bit_shift_equals_the_shipped_pair_row():
         one.simulate(want, eq, scalars=sc)
         new.simulate(got, eq, scalars=sc, fixed={})
         assert all(np.array_equal(a, b) for a, b in zip(want, got)), trial
+
+
+@pytest.mark.parametrize("nw,groups", [(1, 1), (2, 1), (5, 1), (1, 2), (2, 2), (8, 1), (28, 1)])
+def test_myers_eight_instruction_row_equals_the_ten_instruction_row(nw, groups):
+    """Round 4: myers_body — eight instructions and two carry chains per word, HN read off the carries of VP + (VP & E) — against
+    myers_body10 (rounds 1-3: ten and three), row by row on random states that keep the recurrence's invariant VP & VN = 0 and on
+    random match masks; both are pinned to the oracle by the tests above, this pins them to each other bit for bit."""
+    rng = np.random.default_rng(800 + 10 * nw + groups)
+    old, new = R.myers_body10(nw, groups), R.myers_body(nw, groups)
+    assert new.valu_count() == 8 * nw * groups and old.valu_count() == 10 * nw * groups
+    assert R.count_hazard_nops(new) == 0 and new.allocate_temps()[1] <= 2 * nw
+    assert sum(op.kind in ("add_co", "setc1") for op in new.ops) == 2 * groups        # two chains per group (three before)
+    st = []
+    for _ in range(nw * groups):
+        vp = rng.integers(0, 2**32, 64, dtype=np.uint32)
+        st += [vp, rng.integers(0, 2**32, 64, dtype=np.uint32) & ~vp]
+    a, b = [x.copy() for x in st], [x.copy() for x in st]
+    for row in range(200):
+        eq = [rng.integers(0, 2**32, 64, dtype=np.uint32) & rng.integers(0, 2**32, 64, dtype=np.uint32) for _ in range(nw * groups)]
+        old.simulate(a, eq)
+        new.simulate(b, eq)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), row
+        assert all(not (b[2 * w] & b[2 * w + 1]).any() for w in range(nw * groups))      # the invariant survives
