@@ -3,29 +3,28 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
-One "step" = one pass of the hot path over the whole workload: every query against every resident
-subject of this rank (BASELINE.json configs[1] by default: Myers unit-cost global, 10k queries x 1M
-subjects, 150 bp).  Inputs (mapped queries, Peq blocks) are resident in HBM before the timed region;
-scores stay in HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed / RCCL):
+One "step" = one pass of the hot path over the whole workload: every query against every subject of the job's bucket
+(BASELINE.json configs[1] by default: Myers unit-cost global, 10k queries x 1M subjects, 150 bp).  Inputs (mapped queries, Peq
+blocks) are resident in HBM before the timed region.  The job is the SAME at every N ("scaling": "strong"):
 
-  * configs 2-4: weak scaling — every rank owns a full 1M-subject bucket, the query set is broadcast
-    from rank 0 once, no collective in the timed region (the reference has none on this path);
-  * config 5 (BASELINE: "1k x 1M x 1000 bp sharded across 8 MI355X"): strong scaling — ONE 1M-subject
-    bucket cut into contiguous slices with plan_shards (the KNC backend's dispatch_task), so the
-    problem is the same at every N.
+  * N = 1: the whole bucket on the one GPU, one launch per step, scores stay in HBM (nothing to gather);
+  * N > 1 (one rank per GPU, torch.distributed / RCCL): the bucket is cut into contiguous slices by plan_shards (the KNC
+    backend's dispatch_task, BGSA_KNC/global.c:374-431), the query set is broadcast from rank 0 once, and a step is, per block of
+    GATHER_BLOCK_ROWS queries, the kernel on the rank's slice + its tile handed to the streamed gather (ScoreGatherStream: a side
+    stream sends it to rank 0 while the next block is scored; cal_mic.c:121-147, 535-536), then drain() — the gather is INSIDE the
+    timed region, so `value` is what the node delivers to rank 0, not what its kernels could.  Beside it: `kernel_only` (one launch
+    per pass, no transfer: the reference's "cal"), `gather_blocks_of_100` (the same mechanism in the reference's block size),
+    `weak` (rounds 1-4's headline: a full bucket per rank, kernels only — linear in N by construction) and `config5_sharded`
+    (BASELINE configs[4]: 1k x 1M x 1000 bp cut the same way, kernel-only and with the streamed gather).
 
-`value` is the kernel-path rate (the reference's "cal GCUPS", cal_cpu.c:472); beside it the line carries
-`total_gcups` (raw rows on the host -> scores on the host, the whole job in reference-sized blocks: H2D + GPU
-preprocess + kernel + D2H, the reference's "Total GCUPS", cal_cpu.c:473-474) and, for N > 1,
-`gather` (the same steps with the per-block score gather to rank 0 over xGMI streamed beside them).
+`value` is the reference's formula over the max-over-ranks wall time of the timed steps (cal_cpu.c:472); beside it the line
+carries `total_gcups` (N = 1: raw rows on the host -> scores on the host, the whole job in reference-sized blocks: H2D + GPU
+preprocess + kernel + D2H, the reference's "Total GCUPS", cal_cpu.c:473-474).
 
-The default invocation (config 2) also carries the other BASELINE GPU configs, so that the ONE line the driver
-runs has a driver-timed number for each of them:
-
-  * N = 1: `other_configs` — configs 3 (planted mix), 4 and 5, one warm-up + two passes each, after the timed region;
-  * N > 1: `strong` — config 5 (1k x 1M x 1000 bp) as ONE bucket cut by plan_shards over the N ranks (the KNC
-    backend's dispatch_task, BGSA_KNC/global.c:374-431; per-device offload + download, cal_mic.c:121-147):
-    kernel-only, and with the streamed per-block gather to rank 0.
+The default invocation at N = 1 also carries the other BASELINE GPU configs — `other_configs`: configs 3 (planted mix), 4 and 5, one
+warm-up + two passes each after the timed region, each with the reference's CPU path for that config timed on this node's host
+cores (`cpu_baseline`, 64 threads) — and the utilisation figures as scalars (`roofline.issued_frac`, `.issued_frac_sustained`,
+`.valu_per_wave_row`, `.cfg<N>_*`; `cpu_baseline.cfg<N>_value`).
 
 The whole run sits under a watchdog that is armed BEFORE init_process_group: a hang (RCCL init, a collective, a
 kernel) ends with rank 0 printing what it has, `"rccl_ok": false`, and every rank leaving with status 3.
@@ -58,12 +57,19 @@ HBM_PEAK = 8.0e12
 REF_BUCKET_COUNT = 100   # queries per block of the reference's pipeline (original/BGSA_CPU/config.h:13)
 
 CONFIGS = {
-    # id: (algo, name, nq, ns, length, k, scaling)
-    2: (B.ALGO_MYERS, "Myers unit-cost global, 10k queries x 1M subjects, 150 bp", 10_000, 1_000_000, 150, 0, "weak"),
-    3: (B.ALGO_BANDED, "Banded Myers e=8, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 8, "weak"),
-    4: (B.ALGO_BITPAL, "BitPAl packed M=2/I=-3/G=-5, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 0, "weak"),
+    # id: (algo, name, nq, ns, length, k, scaling).  Every config is ONE job whatever N: at N > 1 its subject bucket is cut
+    # by plan_shards over the ranks (the KNC backend's dispatch_task) — total work fixed as N grows = "strong".
+    2: (B.ALGO_MYERS, "Myers unit-cost global, 10k queries x 1M subjects, 150 bp", 10_000, 1_000_000, 150, 0, "strong"),
+    3: (B.ALGO_BANDED, "Banded Myers e=8, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 8, "strong"),
+    4: (B.ALGO_BITPAL, "BitPAl packed M=2/I=-3/G=-5, 10k x 1M, 150 bp", 10_000, 1_000_000, 150, 0, "strong"),
     5: (B.ALGO_MYERS, "Myers multi-word 1000 bp, 1k queries x 1M subjects sharded over the GPUs", 1_000, 1_000_000, 1000, 0, "strong"),
 }
+# Query rows per block of the sharded run's streamed gather (N > 1).  The reference's pipeline moves REF_BUCKET_COUNT = 100 query rows
+# per block (a constant of its config.h, sized for host memory); a device backend's config.h sets its own, and with 288 GB of HBM
+# per GPU and point-to-point xGMI links the block is sized for the transfer: 1,000 rows = 250 MB per peer and block at N = 8
+# (fewer, larger transfers; a launch of 1,000 x 125k pairs holds 60 tasks per wave slot where 100 rows hold six).  The line
+# carries the reference-sized blocks beside it (`gather_blocks_of_100`).  BGSA_BENCH_BLOCK_ROWS overrides.
+GATHER_BLOCK_ROWS = int(os.environ.get("BGSA_BENCH_BLOCK_ROWS", "1000"))
 
 # Subject mixes of the banded filter (config 3).  Its work is data dependent: a wave stops as soon as every
 # one of its 64 lanes is past the error limit, so the rate depends on how many pairs survive and how they
@@ -124,6 +130,21 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
     return None
 
 
+ISSUED_SCALARS = ("issued_frac", "issued_frac_sustained", "valu_per_wave_row")
+
+
+def flat_issued(issued: dict | None) -> dict:
+    """The utilisation figures of an `issued` object as scalars, under the names every entry of the line uses (the headline's
+    `roofline` and each of `other_configs`): a reader — or a parser — that keeps only the scalars of an object still has the
+    figure that is <= 1.  issued_frac = VALU instructions issued x 64 lanes / kernel time / peak at the nominal 2.4 GHz,
+    issued_frac_sustained = the same against the clock the chip held, valu_per_wave_row = instructions per (query row, wave)."""
+    if not issued:
+        return {name: None for name in ISSUED_SCALARS} | {"issued_source": None}
+    return {"issued_frac": issued.get("frac"), "issued_frac_sustained": issued.get("frac_at_sustained_clock"),
+            "valu_per_wave_row": issued.get("valu_per_nominal_wave_row", issued.get("valu_per_row")),
+            "issued_source": issued.get("source")}
+
+
 KERNEL_SOURCES = {   # what defines the scoring kernel of an algorithm: its id stamps PMC passes and the bench line
     B.ALGO_MYERS: ("myers_global.hip", "myers_rows_gen.inc", "bgsa_common.h"),
     B.ALGO_BANDED: ("banded.hip", "banded_rows_gen.inc", "bgsa_common.h"),
@@ -161,7 +182,7 @@ def pmc_values(config: int, tag: str = "", source_id: str | None = None):
     return vals, Path(files[-1]).name
 
 
-def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> dict:
+def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int, thread_counts=None, budget_s: float | None = None) -> dict:
     """Time the CPU path on a bounded sample of the same workload, on this node's host cores.
 
     Myers: north_star asks for "BGSA's own AVX2 CPU path".  Upstream commits the Myers kernel as its SSE instance only
@@ -181,7 +202,7 @@ def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> d
     ns, slen = s_rows.shape
     cells = float(nq) * ns * qlen * slen
     sample = f"first {nq} queries x first {ns} subjects of the bench workload, {slen} bp"
-    budget = float(os.environ.get("BGSA_BENCH_CPU_SECONDS", "45"))
+    budget = float(os.environ.get("BGSA_BENCH_CPU_SECONDS", "45")) if budget_s is None else budget_s
     t0 = time.time()
     found = []
     for variant in variants:
@@ -192,7 +213,7 @@ def cpu_baseline(q_rows: np.ndarray, s_rows: np.ndarray, algo: int, k: int) -> d
             # thread counts on the same sample, each by the reference's own cal timer (a quarter of the hardware
             # threads won on every box so far: it goes first, so that a tight budget still sees it)
             tried, best = {}, None
-            for n_thr in sorted({max(1, threads // 4), max(1, threads // 2), threads}):
+            for n_thr in (thread_counts or sorted({max(1, threads // 4), max(1, threads // 2), threads})):
                 _, out = O.run_reference(variant, q_rows, s_rows, threads=n_thr, k=(k if algo == B.ALGO_BANDED else None),
                                          want_scores=False, tmp_root="/dev/shm" if Path("/dev/shm").is_dir() else None)
                 r = O.parse_gcups(out)
@@ -445,7 +466,12 @@ def preflight(dist, dev, rank, world, local_rank):
     return info
 
 
-def side_config(cfg_id, dev, L, nq=None, ns=None, passes=2, mix="planted", rank=0, dist=None, keep=False):
+# CPU samples of the other configs' reference baselines (queries x subjects of the config's own workload), sized for <= 10 s each at
+# 64 threads on the GPU box's host: banded ~2,100 GCUPS, BitPAl ~165, Myers 1000 bp ~1,900 (AVX2 instance) / ~950 (SSE)
+OTHER_CPU_SAMPLES = {3: (2000, 200_000), 4: (400, 100_000), 5: (100, 50_000)}
+
+
+def side_config(cfg_id, dev, L, nq=None, ns=None, passes=2, mix="planted", rank=0, dist=None, keep=False, cpu=False):
     """One more BASELINE config inside the same line: workload resident in HBM, one warm-up pass, `passes` passes
     timed with HIP events on the launch stream.  Returns the entry (and, with keep, the live objects for a
     further leg)."""
@@ -491,6 +517,25 @@ def side_config(cfg_id, dev, L, nq=None, ns=None, passes=2, mix="planted", rank=
     else:
         entry["issued"] = {"frac": None, "source": pmc_src or "no PMC pass for this config and mix"}
     entry["roofline_frac_reference_ops"] = round(entry["gcups"] * 1e9 * algorithmic_ops_per_cell(algo, length, k) / VALU_PEAK_OPS, 4)
+    # the same three scalars as the headline's `roofline` object
+    if pmc and "SQ_INSTS_VALU" in pmc:
+        entry["issued"]["valu_per_nominal_wave_row"] = round(pmc["SQ_INSTS_VALU"] / (float(nq) * (ns_pad // 64) * length), 3)
+    elif vpr and exact:
+        entry["issued"]["valu_per_row"] = vpr
+    entry.update(flat_issued(entry["issued"]))  # issued_frac_sustained stays None: the clock probes run beside the headline's timed region only
+    if cpu:
+        # the reference's own CPU path for this config on this node's host cores, in the same run (north_star): 64 threads —
+        # the count that won every thread sweep of rounds 3-4 on these hosts — by the reference's cal timer (cal_cpu.c:111-118,472)
+        try:
+            cq, cs = OTHER_CPU_SAMPLES[cfg_id]
+            cq, cs = min(cq, nq), min(cs, ns) // 8 * 8
+            threads = min(64, os.cpu_count() or 1)
+            base = cpu_baseline(q_rows[:cq].cpu().numpy(), s_rows[:cs, :length].cpu().numpy(), algo, k, thread_counts=[threads], budget_s=12.0)
+            base["gpu_over_cpu"] = round(entry["gcups"] / base["value"], 1)
+            base["value"] = round(base["value"], 2)
+            entry["cpu_baseline"] = base
+        except Exception as e:
+            entry["cpu_baseline"] = {"error": repr(e)}
     if keep:
         return entry, (a, out, q_rows, s_rows, ns_pad)
     del a, out, q_rows, s_rows
@@ -520,7 +565,9 @@ def main() -> int:
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1, config 2: do not time configs 3 / 4 / 5 after the timed region (set it under a profiler)")
     ap.add_argument("--no-strong", action="store_true",
-                    help="N > 1, config 2: do not run the config-5 strong-scaling leg (one bucket cut by plan_shards)")
+                    help="N > 1, config 2: do not run the config-5 leg (its 1000 bp bucket cut by plan_shards: `config5_sharded`)")
+    ap.add_argument("--no-weak", action="store_true",
+                    help="N > 1, config 2: do not run the weak-scaling side leg (a full bucket per rank, kernels only: `weak`)")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not run the sustained-clock probe waves beside the timed kernels (set it under rocprofv3 --pmc, "
                          "which may serialise kernels: the probes then delay the launch they are meant to observe)")
@@ -577,12 +624,8 @@ def main() -> int:
 
     # ---- this rank's subjects -----------------------------------------------------------------------------
     from bgsa_amd.multi_gpu import ScoreGatherStream, plan_shards
-    if scaling == "strong":
-        shards = plan_shards(ns_total, world)        # one bucket, contiguous slices (dispatch_task)
-        ns = shards[rank].count
-    else:
-        shards = None
-        ns = ns_total                                # every rank its own full bucket
+    shards = plan_shards(ns_total, world)            # ONE bucket, contiguous slices, multiples of 64 (dispatch_task, BGSA_KNC/global.c:374-431)
+    ns = shards[rank].count
     wd.stage = "workload + query broadcast"
     q_rows, s_rows, ns_pad = make_workload(args.config, algo, nq, ns, length, k, mix, rank, dev, dist)
 
@@ -656,33 +699,110 @@ def main() -> int:
         return elapsed, float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) / 1e3
 
     clock_box = [None]
-    wd.stage = "timed region"
-    elapsed, kernel_s = timed(lambda: aligner.score(0, nq, out=out), args.steps, args.warmup, probe=True)
-    clock = clock_box[0]
-    # The probes must not cost anything.  If the wall time of the timed region is not the kernels' time (events on the launch
-    # stream) plus launch overhead, something held the launches back — the probes, on a box where they do not run beside the
-    # caller's stream after all — and the region is timed again without them; the line then says so instead of carrying a clock.
-    probe_note = None
-    if clock is not None:
-        slow = elapsed > 1.25 * kernel_s * args.steps + 0.05
-        if dist is not None:
-            flag = torch.tensor([1 if slow else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            slow = bool(flag.item())
-        if slow:
-            probe_note = (f"timed region took {elapsed:.3f} s with the clock probes against {kernel_s * args.steps:.3f} s of kernel time: "
-                          "timed again without them")
-            use_probe = False
-            elapsed, kernel_s = timed(lambda: aligner.score(0, nq, out=out), args.steps, 0, probe=False)
-            clock = None
+    one_launch = lambda: aligner.score(0, nq, out=out)     # noqa: E731  every query against the rank's resident subjects
+    kernel_only = None
+    gs = None
+    n_blocks_step = -(-nq // GATHER_BLOCK_ROWS)
+    if world > 1:
+        # ---- N > 1.  The job is the SAME bucket as at N = 1, cut over the ranks; what has to be true at the end of a step is
+        # what the reference's multi-device host has (cal_mic.c:121-147, 535-536): every device's result tiles of every query
+        # block on the host device, rank 0.  So the timed step is: per block of GATHER_BLOCK_ROWS queries the kernel on the
+        # rank's slice, its tile handed to the streamed gather (ScoreGatherStream.submit: a side stream sends it to rank 0
+        # while the next block is scored), and drain() at the end — the gather is INSIDE the timed region.
+        # First, kernels only (the reference's `cal`: one launch over all queries, nothing moved): the side key `kernel_only`.
+        wd.stage = "kernel-only leg"
+        ko_elapsed, kernel_s = timed(one_launch, 2, 1)
+        aligner.check_faults()
+        kernel_only = {"what": "one launch per pass over all queries on every rank's slice, no transfer (the reference's cal timer); max over ranks",
+                       "passes": 2, "ms_per_pass": round(ko_elapsed / 2 * 1e3, 3),
+                       "gcups": round(float(nq) * ns_total * length * length * 2 / ko_elapsed / 1e9, 2)}
+        wd.extra["kernel_only"] = kernel_only          # a watchdog that fires in the gathered region still prints this
+        q_tile_used = int(L.bgsa_hip_last_query_tile())
+        wd.stage = "gather set-up"
+        setup_error = None
+        try:
+            gs = ScoreGatherStream(dist, dev, [sh.count for sh in shards], aligner.out_dtype, block_rows=GATHER_BLOCK_ROWS)
+        except Exception as e:      # can only fail locally (allocation): agree on it before anyone enters a transfer the others would wait for
+            setup_error = repr(e)
+        ok = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            print(f"[bench] rank {rank}: gather set-up failed ({setup_error or 'on another rank'})", file=sys.stderr)
+            return 4
+
+        def gathered_step():
+            for lo in range(0, nq, GATHER_BLOCK_ROWS):
+                hi = min(nq, lo + GATHER_BLOCK_ROWS)
+                aligner.score(lo, hi, out=out[lo:hi])
+                gs.submit(out[lo:hi, :ns])
+            gs.drain()
+
+        # An interconnect problem shows as a hang, not an exception: if the gathered region has not finished in time, rank 0 prints
+        # a line without a value (the job's figure does not exist) that carries `kernel_only`, gather_ok = false, and every rank
+        # leaves with a NON-ZERO status.
+        g_limit = float(os.environ.get("BGSA_BENCH_GATHER_TIMEOUT", "300"))
+
+        def mark_gather(line):
+            line["gather"] = {"error": f"the timed region (kernels + streamed gather) did not finish within {g_limit:.0f} s; "
+                                       "`kernel_only` is what was measured"}
+            line["gather_ok"] = False
+
+        wd.stage = "timed region (kernels + streamed gather to rank 0)"
+        gather_timer = wd.leg(g_limit, f"the gathered timed region did not finish within {g_limit:.0f} s", mark_gather)
+        elapsed, step_s = timed(gathered_step, args.steps, args.warmup, probe=True)
+        gather_timer.cancel()
+        clock = clock_box[0]
+        probe_note = None
+    else:
+        wd.stage = "timed region"
+        elapsed, kernel_s = timed(one_launch, args.steps, args.warmup, probe=True)
+        clock = clock_box[0]
+        # The probes must not cost anything.  If the wall time of the timed region is not the kernels' time (events on the launch
+        # stream) plus launch overhead, something held the launches back — the probes, on a box where they do not run beside the
+        # caller's stream after all — and the region is timed again without them; the line then says so instead of carrying a clock.
+        probe_note = None
+        if clock is not None:
+            slow = elapsed > 1.25 * kernel_s * args.steps + 0.05
+            if dist is not None:
+                flag = torch.tensor([1 if slow else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                slow = bool(flag.item())
+            if slow:
+                probe_note = (f"timed region took {elapsed:.3f} s with the clock probes against {kernel_s * args.steps:.3f} s of kernel time: "
+                              "timed again without them")
+                use_probe = False
+                elapsed, kernel_s = timed(one_launch, args.steps, 0, probe=False)
+                clock = None
+        q_tile_used = int(L.bgsa_hip_last_query_tile())
     aligner.check_faults()
     wd.stage = "after the timed region"
+
+    # ---- N > 1: did the blocks arrive?  One more block after the timed region, checked end to end: every rank sums the tile it
+    # sent, rank 0 sums the segment that arrived in its block buffer (the reference's per-device block layout).
+    gather_check = None
+    if gs is not None:
+        wd.stage = "gather content check"
+        hi = min(nq, GATHER_BLOCK_ROWS)
+        aligner.score(0, hi, out=out[:hi])
+        gs.submit(out[:hi, :ns])
+        gs.drain()
+        sent = [None] * world
+        dist.all_gather_object(sent, int(out[:hi, :ns].sum(dtype=torch.int64).item()))
+        if rank == 0:
+            blk = gs.last_block()
+            got, off = [], 0
+            for sh in shards:
+                got.append(int(blk[off:off + hi * sh.count].sum(dtype=torch.int64).item()))
+                off += hi * sh.count
+            gather_check = {"segments_ok": got == sent, "rows": hi, "segment_sums_sent": sent if got != sent else None,
+                            "segment_sums_at_root": got if got != sent else None,
+                            "what": "one block after the timed region: per rank the int64 sum of the tile it sent against the sum of its "
+                                    "segment of rank 0's block buffer"}
 
     # ---- HBM traffic of one launch, modelled from the launch geometry: every query tile re-reads the rank's Peq / Mext
     # blocks once, every score is written once, every stream read once per subject workgroup column (L2-resident: not
     # counted).  Where a PMC pass exists (N = 1) the counters check the model; per rank at N > 1 the model is what
     # there is (config 5: does the ratio grow when eight GPUs' slices shrink? — it depends on the tile, not the slice).
-    q_tile_used = int(L.bgsa_hip_last_query_tile())
     traffic_model = None
     if q_tile_used > 0 and "blocked" not in aligner.kernel_name():
         peq_bytes = B.group_words(algo, aligner.wn, k) * 4 * (ns_pad // 64)
@@ -706,7 +826,7 @@ def main() -> int:
     checksum = checksum_int64(out, ns) if rank == 0 else 0
     survivors = int((out[:, :ns] != 127).sum().item()) if (rank == 0 and algo == B.ALGO_BANDED) else None
 
-    n_subjects_job = ns_total if scaling == "strong" else ns * world
+    n_subjects_job = ns_total
     cells_per_step_rank = float(nq) * ns * length * length
     cells_per_step_job = float(nq) * n_subjects_job * length * length
     gcups = cells_per_step_job * args.steps / elapsed / 1e9
@@ -761,8 +881,13 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": cfg_name + (" [SIZE OVERRIDDEN]" if overridden else ""), "queries": nq,
                        "subjects_total": n_subjects_job, "subjects_this_rank": ns, "length_bp": length, "k": k,
-                       "parallelism": f"subject-sharded x{world} ({scaling} scaling)",
+                       "parallelism": (f"one bucket cut by plan_shards over {world} ranks; per block of {GATHER_BLOCK_ROWS} queries the kernel on "
+                                       f"the rank's slice + its tile streamed to rank 0 (inside the timed region)") if world > 1
+                                      else "one GPU: the whole bucket, one launch per step",
+                       "gather_block_rows": GATHER_BLOCK_ROWS if world > 1 else None,
                        "kernel": aligner.kernel_name(), "word_num": wn, "kernel_source_id": src_id},
+            # N > 1: `value` includes the streamed gather; this is the kernels alone (one launch per pass, max over ranks)
+            "kernel_only": kernel_only,
             "clock": clock if clock is not None else ({"sustained_mhz": None, "note": probe_note} if probe_note else None),
             "ranks_seen": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["device_index"], r["pid"]) for r in ranks_info}),
             "ranks": ranks_info,
@@ -783,6 +908,9 @@ def main() -> int:
                 "frac": round(frac, 4),
                 "ops_per_cell_reference": round(ops_cell, 4),
                 "ops_note": None,
+                # the utilisation figures as scalars of this object (a parser that keeps only scalars keeps these): VALU instructions
+                # issued x 64 lanes / kernel time / peak, at the nominal and at the sustained clock; instructions per (query row, wave)
+                **flat_issued(issued),
                 "issued": issued,
                 "traffic": traffic,
                 "traffic_source": pmc_src if (traffic or pmc is None) else None,
@@ -813,80 +941,107 @@ def main() -> int:
     print_lock = wd.lock
     if rank == 0:
         wd.result = result          # from here on a firing watchdog prints the measured line, not a stub
-    gather_wanted = dist is not None and world > 1 and os.environ.get("BGSA_BENCH_GATHER", "1") != "0"
-    gather_timer = None
-    if gather_wanted:
-        # An interconnect problem shows as a hang, not an exception: if this optional leg has not finished in time,
-        # rank 0 still prints the measured line (kernel-only value, gather marked as timed out) and every rank leaves
-        # with a NON-ZERO status — a leg that hung on the interconnect or the GPU is not a clean run.
-        limit = float(os.environ.get("BGSA_BENCH_GATHER_TIMEOUT", "180"))
+    # ---- N > 1: what the timed region moved, and the same steps in the reference's own block size beside it ----------------
+    if world > 1:
+        gather_info = None
+        if rank == 0:
+            gather_info = {"what": f"inside the timed region: {n_blocks_step} blocks of {GATHER_BLOCK_ROWS} queries per step — kernel per block on every "
+                                   "rank's slice, the tiles of all ranks to rank 0 in the reference's per-device block layout (cal_mic.c:535-536), "
+                                   "grouped send/recv on a side stream beside the next block's kernel, two block buffers",
+                           "block_rows": GATHER_BLOCK_ROWS, "blocks_per_step": n_blocks_step,
+                           "bytes_to_root_per_block": int(sum(sh.count for sh in shards[1:]) * min(nq, GATHER_BLOCK_ROWS) * out.element_size()),
+                           "bytes_to_root_per_step": int(sum(sh.count for sh in shards[1:]) * nq * out.element_size()),
+                           "root_blocks_received": gs.n_submitted,
+                           "gcups_with_gather": round(gcups, 2), "gcups_kernels_only": kernel_only["gcups"],
+                           "content_check": gather_check}
+        small_wanted = os.environ.get("BGSA_BENCH_GATHER", "1") != "0" and GATHER_BLOCK_ROWS != REF_BUCKET_COUNT
+        small_info = None
+        if small_wanted:
+            # The reference moves REF_BUCKET_COUNT = 100 query rows per block: ten such blocks, with and without the gather (an
+            # optional leg under a limit of its own: its expiry keeps the measured value and marks the leg)
+            limit = float(os.environ.get("BGSA_BENCH_SMALL_GATHER_TIMEOUT", "120"))
+            small_timer = wd.leg(limit, f"the reference-sized gather leg did not finish within {limit:.0f} s",
+                                 lambda line: line.__setitem__("gather_blocks_of_100", {"error": f"did not finish within {limit:.0f} s"}))
+            wd.stage = "gather leg, reference-sized blocks"
+            try:
+                gs100 = ScoreGatherStream(dist, dev, [sh.count for sh in shards], aligner.out_dtype, block_rows=REF_BUCKET_COUNT)
+                nq_g = min(nq, 10 * REF_BUCKET_COUNT)
 
-        def mark_gather(line):
-            line["gather"] = {"error": f"gather leg did not finish within {limit:.0f} s; value is the kernel-only figure"}
-            line["gather_ok"] = False
+                def blocks100(submit):
+                    for lo in range(0, nq_g, REF_BUCKET_COUNT):
+                        hi = min(nq_g, lo + REF_BUCKET_COUNT)
+                        aligner.score(lo, hi, out=out[lo:hi])
+                        if submit:
+                            gs100.submit(out[lo:hi, :ns])
+                    if submit:
+                        gs100.drain()
 
-        wd.stage = "gather leg"
-        gather_timer = wd.leg(limit, f"gather leg did not finish within {limit:.0f} s", mark_gather)
-    if gather_wanted:
-        # set-up can only fail locally (allocation): agree on it before anyone enters a transfer the others would wait for
-        all_shards = shards if shards is not None else [type("S", (), {"start": r * ns, "count": ns})() for r in range(world)]
-        gs, setup_error = None, None
+                g_elapsed, _ = timed(lambda: blocks100(True), 1, 1)
+                k_elapsed, _ = timed(lambda: blocks100(False), 1, 1)
+                cells_g = float(nq_g) * ns_total * length * length
+                small_info = {"what": f"{-(-nq_g // REF_BUCKET_COUNT)} blocks of {REF_BUCKET_COUNT} queries (the reference's REF_BUCKET_COUNT), same "
+                                      "mechanism, after the timed region",
+                              "gcups_with_gather": round(cells_g / g_elapsed / 1e9, 1),
+                              "gcups_kernels_only_same_blocks": round(cells_g / k_elapsed / 1e9, 1),
+                              "bytes_to_root_per_block": int(sum(sh.count for sh in shards[1:]) * REF_BUCKET_COUNT * out.element_size()),
+                              "root_blocks_received": gs100.n_submitted}
+                del gs100
+            except Exception as e:      # an optional leg never takes the measured line with it
+                small_info = {"error": repr(e)}
+            small_timer.cancel()
+        if rank == 0:
+            with print_lock:
+                result["gather"] = gather_info
+                result["gather_ok"] = bool(gather_check and gather_check["segments_ok"])
+                if small_info is not None:
+                    result["gather_blocks_of_100"] = small_info
+
+    # ---- N > 1, the default invocation: the weak-scaling figure of rounds 1-4 as a side key — every rank a full bucket of its
+    # own (config 2: 1M subjects per rank, job = N x 1M), kernels only.  It is linear in N by construction; it says what the
+    # ranks do when nothing is shared, nothing about the gather.
+    if dist is not None and world > 1 and args.config == 2 and not args.no_weak and args.length is None:
+        wd.stage = "weak leg (a full bucket per rank)"
+        weak, err = None, None
+        weak_limit = float(os.environ.get("BGSA_BENCH_WEAK_TIMEOUT", "180"))
+        weak_timer = wd.leg(weak_limit, f"weak leg did not finish within {weak_limit:.0f} s",
+                            lambda line: line.__setitem__("weak", {"error": f"did not finish within {weak_limit:.0f} s"}))
         try:
-            gs = ScoreGatherStream(dist, dev, [s.count for s in all_shards], aligner.out_dtype, block_rows=REF_BUCKET_COUNT)
+            del out
+            aligner = None
+            gs = None
+            torch.cuda.empty_cache()
+            w_entry, (wa, wout, _wq, _ws, _) = side_config(2, dev, L, nq=args.nq, ns=args.ns, passes=1, rank=rank, dist=dist, keep=True)
+            w_el, w_ks = timed(lambda: wa.score(0, nq, out=wout), 2, 0)
+            wa.check_faults()
+            weak = {"what": "every rank scores all queries against a full bucket of its own (rounds 1-4's headline at N > 1): kernels only, "
+                            "no transfer; job = N buckets",
+                    "scaling": "weak", "subjects_per_rank": ns_total, "subjects_total": ns_total * world, "passes": 2,
+                    "ms_per_pass": round(w_el / 2 * 1e3, 3),
+                    "gcups": round(float(nq) * ns_total * world * length * length * 2 / w_el / 1e9, 1)}
+            del wa, wout, _wq, _ws
+            torch.cuda.empty_cache()
         except Exception as e:
-            setup_error = repr(e)
-        try:
-            ok = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                gather_info = {"error": setup_error or "set-up failed on another rank"}
-        except Exception as e:   # a peer that is gone (e.g. its watchdog fired first) must not take the line with it
-            gather_info = {"error": repr(e)}
-    if gather_info is None and gather_wanted:
-        try:
-            nq_g = min(nq, 10 * REF_BUCKET_COUNT)     # ten reference-sized blocks are enough to see the steady state
-
-            def gather_step():
-                for lo in range(0, nq_g, REF_BUCKET_COUNT):
-                    hi = min(nq_g, lo + REF_BUCKET_COUNT)
-                    aligner.score(lo, hi, out=out[lo:hi])
-                    gs.submit(out[lo:hi, :ns])
-                gs.drain()
-
-            g_elapsed, _ = timed(gather_step, 1, 1)
-            k_elapsed, _ = timed(lambda: [aligner.score(lo, min(nq_g, lo + REF_BUCKET_COUNT), out=out[lo:lo + REF_BUCKET_COUNT])
-                                          for lo in range(0, nq_g, REF_BUCKET_COUNT)], 1, 1)
-            cells_g = float(nq_g) * (ns_total if scaling == "strong" else ns * world) * length * length
-            gather_info = {"what": f"{(nq_g + REF_BUCKET_COUNT - 1) // REF_BUCKET_COUNT} blocks of {REF_BUCKET_COUNT} queries: kernel per "
-                                   f"block, tiles of all ranks to rank 0 in the reference's per-device block layout "
-                                   f"(cal_mic.c:535-536), grouped send/recv on a side stream, double-buffered",
-                           "gcups_with_gather": round(cells_g / g_elapsed / 1e9, 1),
-                           "gcups_kernels_only_same_blocks": round(cells_g / k_elapsed / 1e9, 1),
-                           "bytes_to_root_per_block": int(sum(s.count for s in all_shards[1:]) * REF_BUCKET_COUNT * out.element_size()),
-                           "root_blocks_checked": gs.blocks_checked}
-        except Exception as e:  # never let the optional leg break the benchmark line
-            gather_info = {"error": repr(e)}
-
-    if gather_timer is not None:
-        gather_timer.cancel()
-    if rank == 0 and gather_info:
-        with print_lock:
-            result["gather"] = gather_info
-            result["gather_ok"] = "error" not in gather_info
+            err = repr(e)
+        weak_timer.cancel()
+        if rank == 0:
+            with print_lock:
+                result["weak"] = weak if weak is not None else {"error": err}
 
     # ---- N > 1, the default invocation: BASELINE configs[4] — ONE 1M-subject bucket of 1000 bp reads cut by plan_shards
     # over the ranks (dispatch_task, BGSA_KNC/global.c:374-431; per-device offload + result download, cal_mic.c:121-147) —
     # kernel-only and with the streamed per-block gather, so that a SCALE run times the north star's sharded config too.
     if dist is not None and world > 1 and args.config == 2 and not args.no_strong and args.length is None:
-        wd.stage = "strong leg (config 5 sharded)"
+        wd.stage = "config 5 sharded"
         strong, err = None, None
         strong_limit = float(os.environ.get("BGSA_BENCH_STRONG_TIMEOUT", "300"))
         # as for the gather leg: a rank that fails here while its peers wait in a collective shows as a hang, and the
         # measured line must still go out (marked), with every rank leaving non-zero
         strong_timer = wd.leg(strong_limit, f"strong leg did not finish within {strong_limit:.0f} s",
-                              lambda line: line.__setitem__("strong", {"error": f"did not finish within {strong_limit:.0f} s"}))
+                              lambda line: line.__setitem__("config5_sharded", {"error": f"did not finish within {strong_limit:.0f} s"}))
         try:
-            del out
+            out = None
+            aligner = None
+            gs = None
             torch.cuda.empty_cache()
             algo5, name5, cfg_nq5, cfg_ns5, len5, _, _ = CONFIGS[5]
             nq5, ns5 = args.nq or cfg_nq5, args.ns or cfg_ns5
@@ -931,7 +1086,7 @@ def main() -> int:
         strong_timer.cancel()
         if rank == 0:
             with print_lock:
-                result["strong"] = strong if strong is not None else {"error": err}
+                result["config5_sharded"] = strong if strong is not None else {"error": err}
 
     # ---- config 3, one GPU: the other subject mixes (same kernel, same sizes) ---------------------------------
     if algo == B.ALGO_BANDED and world == 1 and args.banded_variants and not overridden:
@@ -964,7 +1119,7 @@ def main() -> int:
     if rank == 0 and world > 1:
         result["total_gcups"] = {"skipped": "measured by rank 0 at N = 1 only"}
         result["cpu_baseline"] = {"skipped": "measured by rank 0 at N = 1 only"}
-        result["other_configs"] = {"skipped": "N = 1 only; at N > 1 the line carries `strong` (config 5 sharded)"}
+        result["other_configs"] = {"skipped": "N = 1 only; at N > 1 the line carries `config5_sharded`"}
     if rank == 0:
         if not args.no_total and world == 1:
             wd.stage = "total_gcups leg"
@@ -993,13 +1148,22 @@ def main() -> int:
             for cid in (3, 4, 5):
                 wd.stage = f"other_configs leg: config {cid}"
                 try:
-                    others[str(cid)] = side_config(cid, dev, L, nq=args.nq, ns=args.ns)
+                    others[str(cid)] = side_config(cid, dev, L, nq=args.nq, ns=args.ns, cpu=not args.no_cpu_baseline)
                 except Exception as e:
                     others[str(cid)] = {"error": repr(e)}
             others["what"] = ("BASELINE configs 3 (SURVEY 8(d)'s planted mix), 4 and 5 on this GPU after the timed region: workload "
                               "resident in HBM, one warm-up + two passes each, HIP events on the launch stream")
             others["wall_s"] = round(time.perf_counter() - t_leg, 1)
             result["other_configs"] = others
+            # ... and as scalars of the two objects every reader of the line keeps: `roofline` and `cpu_baseline`
+            for cid in ("3", "4", "5"):
+                e = others[cid]
+                if "error" in e:
+                    continue
+                result["roofline"][f"cfg{cid}_gcups"] = e["gcups"]
+                result["roofline"][f"cfg{cid}_kernel_ms"] = e["kernel_ms"]
+                result["roofline"][f"cfg{cid}_issued_frac"] = e["issued_frac"]
+                result["roofline"][f"cfg{cid}_valu_per_wave_row"] = e["valu_per_wave_row"]
         if not args.no_cpu_baseline and world == 1 and not custom_scores:  # the reference commits 2/-3/-5 only
             wd.stage = "cpu_baseline leg"
             cq, cs = (int(x) for x in args.cpu_sample.split("x"))
@@ -1007,6 +1171,16 @@ def main() -> int:
             result["cpu_baseline"] = cpu_baseline(q_rows[:cq].cpu().numpy(), s_rows[:cs, :length].cpu().numpy(), algo, k)
             result["cpu_baseline"]["gpu_over_cpu"] = round(gcups / result["cpu_baseline"]["value"], 1)
             result["cpu_baseline"]["value"] = round(result["cpu_baseline"]["value"], 2)
+            if isinstance(result["cpu_baseline"].get("sse"), dict):     # the committed SSE build's figure as a scalar beside the derived AVX2 one
+                result["cpu_baseline"]["sse_value"] = result["cpu_baseline"]["sse"]["value"]
+            for cid in ("3", "4", "5"):         # the other configs' baselines (measured in the other_configs leg) as scalars here too
+                b = (result.get("other_configs") or {}).get(cid, {}).get("cpu_baseline") if isinstance(result.get("other_configs"), dict) else None
+                if b and "value" in b:
+                    result["cpu_baseline"][f"cfg{cid}_value"] = b["value"]
+                    result["cpu_baseline"][f"cfg{cid}_kind"] = b["kind"]
+                    result["cpu_baseline"][f"cfg{cid}_cores"] = b["cores"]
+                    if isinstance(b.get("sse"), dict):
+                        result["cpu_baseline"][f"cfg{cid}_sse_value"] = b["sse"]["value"]
         with print_lock:
             if dist is not None:
                 result["rccl_ok"] = True if backend == "nccl" else None    # every collective up to here has returned

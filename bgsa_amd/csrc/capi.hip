@@ -771,20 +771,27 @@ struct ResidentRange {
     bool uploaded = false;
     uint64_t gen = 0;                      // identity of this content: a rewritten range gets a new one
     uint64_t fp = 0;                       // range_fingerprint() of the host bytes the device copy was made from
-    std::vector<unsigned char> shadow;     // strict mode only: those host bytes themselves
+    // those host bytes themselves, where the policy keeps them (wants_shadow): ranges up to kStrictAutoBytes by default, every
+    // range in strict mode.  Immutable once made and shared with the threads' LastRow, so the lock-free path of align_hip
+    // compares against it without the seam lock and without touching anything but the chunk it was handed.
+    std::shared_ptr<const std::vector<unsigned char>> shadow;
 };
 
 // A registered range that the caller rewrites by other means than hip_handle_reads (a memcpy of a saved bucket, a host
-// that builds Peq itself and forgets bgsa_hip_bucket_resident) must not be scored from the stale device copy in silence
-// (SURVEY 8(b) "Ownership": the callee keeps no state between calls; the KNC precedent, BGSA_KNC/cal_mic.c:348-356,
-// justifies residency, not silence).  Every scoring call therefore fingerprints the host range it is about to use —
-// kFingerprintLines cache lines, the first, the last and a golden-ratio (Weyl) sequence of positions in between: a few
-// hundred nanoseconds once the lines are in the calling core's cache — and a range whose fingerprint changed is uploaded
-// again (its cached rows dropped).  The positions must not be an arithmetic progression: a stride of range / n lines is,
-// for n - 1 groups, the group size itself, and every sample then lands in the same plane and word of its group — the last
-// word of the class-N plane, all zeros in every bucket (found by scripts/soak_seams.py: 33 groups, 34 samples).
-// A rewrite that changes none of the sampled lines is only caught by the full comparison of
-// BGSA_HIP_STRICT_RESIDENT=1 / bgsa_hip_set_strict_resident(1), which keeps a host copy of what was uploaded.
+// that builds Peq itself and forgets bgsa_hip_bucket_resident) breaks the contract of include/bgsa_hip.h — a resident range
+// changes only through hip_handle_reads / bgsa_hip_bucket_resident — and the library still tries not to score the stale
+// device copy (SURVEY 8(b) "Ownership": the callee keeps no state between calls; the KNC precedent,
+// BGSA_KNC/cal_mic.c:348-356, justifies residency, not silence).  Two checks, by range size:
+//   * EXACT, ranges up to kStrictAutoBytes (8 MiB; every range under BGSA_HIP_STRICT_RESIDENT=1): the library keeps the host
+//     bytes it uploaded and every scoring call compares the bytes it is about to use against them (memcmp: < 1 ms for a
+//     whole 8 MiB bucket, per call of the coarse seam; a chunk per call of the fine one);
+//   * BEST EFFORT above that: a fingerprint of kFingerprintLines cache lines — the first, the last and a golden-ratio (Weyl)
+//     sequence of positions in between, a few hundred nanoseconds once the lines are in the calling core's cache.  A rewrite
+//     that changes none of the sampled lines is NOT seen: that is what the contract, or strict mode, is for.
+// A range found changed is uploaded again and its cached rows dropped.  The sample positions must not be an arithmetic
+// progression: a stride of range / n lines is, for n - 1 groups, the group size itself, and every sample then lands in the
+// same plane and word of its group — the last word of the class-N plane, all zeros in every bucket (found by
+// scripts/soak_seams.py: 33 groups, 34 samples).
 static constexpr size_t kFingerprintLines = 66;
 static uint64_t range_fingerprint(const unsigned char *p, size_t bytes)
 {
@@ -808,16 +815,22 @@ static uint64_t range_fingerprint(const unsigned char *p, size_t bytes)
     }
     return h;
 }
-static std::atomic<int> g_strict_resident{-1};   // -1: not decided yet (BGSA_HIP_STRICT_RESIDENT)
-static bool strict_resident()
+static constexpr size_t kStrictAutoBytes = 8u << 20;
+static std::atomic<int> g_strict_resident{-2};   // 1: every range keeps its host copy; 0: ranges <= kStrictAutoBytes do (default); -1: none; -2: not decided yet
+static int strict_mode()
 {
     int v = g_strict_resident.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("BGSA_HIP_STRICT_RESIDENT");
-        v = (e && e[0] == '1') ? 1 : 0;
+    if (v < -1) {
+        const char *e = getenv("BGSA_HIP_STRICT_RESIDENT");   // "1": always, "-1": never (the fingerprint alone, a measurement knob), else the default
+        v = (e && e[0] == '1') ? 1 : ((e && e[0] == '-') ? -1 : 0);
         g_strict_resident.store(v, std::memory_order_relaxed);
     }
-    return v == 1;
+    return v;
+}
+static bool wants_shadow(size_t bytes)
+{
+    const int m = strict_mode();
+    return m == 1 || (m == 0 && bytes <= kStrictAutoBytes);
 }
 
 // 32-bit words per (class, lane) of a HOST Peq buffer whose caller passed `word_num`, or -1.  Myers and
@@ -1161,8 +1174,8 @@ static ResidentRange *resident_range(const unsigned char *peq_host, size_t bytes
             // the bytes the device copy was made from must still be there (see range_fingerprint above); strict mode
             // compares every byte of the part this call is about to use
             bool stale = range_fingerprint(r.host, r.bytes) != r.fp;
-            if (!stale && !r.shadow.empty())
-                stale = memcmp(r.shadow.data() + (peq_host - r.host), peq_host, bytes) != 0;
+            if (!stale && r.shadow)
+                stale = memcmp(r.shadow->data() + (peq_host - r.host), peq_host, bytes) != 0;
             if (stale) {
                 g_host.stale_ranges++;
                 g_range_epoch.fetch_add(1, std::memory_order_release);
@@ -1187,15 +1200,14 @@ static ResidentRange *resident_range(const unsigned char *peq_host, size_t bytes
             }
             if (upload_peq(r.dev, r.host, r_groups, w_host, w_dev, s)) die("resident bucket");
             r.fp = range_fingerprint(r.host, r.bytes);
-            if (strict_resident()) {
+            if (wants_shadow(r.bytes)) {
                 // the copy above may still be reading a pageable source through the runtime's staging: the shadow must hold
-                // exactly what travels, so let it finish first (strict mode is a debugging aid, not a fast path)
+                // exactly what travels, so let it finish first (once per upload of a bucket; small ranges by default)
                 if (hipStreamSynchronize(s) != hipSuccess) die("resident bucket");
-                r.shadow.assign(r.host, r.host + r.bytes);
+                r.shadow = std::make_shared<const std::vector<unsigned char>>(r.host, r.host + r.bytes);
                 r.fp = range_fingerprint(r.host, r.bytes);
             } else {
-                r.shadow.clear();
-                r.shadow.shrink_to_fit();
+                r.shadow.reset();
             }
             r.device = g_host.device;
             r.uploaded = true;
@@ -1217,11 +1229,24 @@ int bgsa_hip_set_auto_resident(int on)
 int bgsa_hip_set_strict_resident(int on)
 {
     std::lock_guard<std::mutex> turn(g_seam);
-    g_strict_resident.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_strict_resident.store(on > 0 ? 1 : (on < 0 ? -1 : 0), std::memory_order_relaxed);
     g_range_epoch.fetch_add(1, std::memory_order_release);   // no thread keeps serving from a row checked the other way
-    for (ResidentRange &r : g_host.ranges) {                 // ranges uploaded before the switch get their shadow on the next call
-        if (on && r.uploaded && r.shadow.empty()) r.uploaded = false;
-        if (!on) { r.shadow.clear(); r.shadow.shrink_to_fit(); }
+    // Every range is uploaded again on its next use, under the new policy — and as NEW content: the host bytes may have
+    // changed since the upload in a way the old policy could not see, so the rows cached from the old device copy go too.
+    for (ResidentRange &r : g_host.ranges) {
+        if (r.uploaded) {
+            for (size_t j = 0; j < g_host.rows.size();) {
+                if (g_host.rows[j].range_gen == r.gen) {
+                    g_host.row_bytes -= g_host.rows[j].scores->size;
+                    g_host.rows.erase(g_host.rows.begin() + j);
+                } else {
+                    j++;
+                }
+            }
+            r.gen = g_host.next_gen++;
+            r.uploaded = false;
+        }
+        r.shadow.reset();
     }
     return BGSA_HIP_OK;
 }
@@ -1495,6 +1520,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
         std::string query;
         std::shared_ptr<RowBuf> scores;
         uint64_t range_fp = 0;     // fingerprint of the bucket's host bytes the row was scored from
+        std::shared_ptr<const std::vector<unsigned char>> shadow;   // those bytes themselves where the policy keeps them (ResidentRange::shadow)
     };
     static thread_local LastRow last;
     if (chunk_read_num > 0 && ref && read && results && ref_len > 0) {
@@ -1508,8 +1534,13 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 (peq_host - last.range_host) % last.group_bytes == 0 && memcmp(&last.params, &params, sizeof params) == 0 &&
                 memcmp(last.query.data(), ref, ref_len) == 0 &&
                 // the bucket's bytes are still the ones this row was scored from (a rewrite the library was not told about
-                // sends the call down the locked path, which uploads the range again); strict mode always takes that path
-                !strict_resident() && range_fingerprint(last.range_host, last.range_bytes) == last.range_fp) {
+                // sends the call down the locked path, which uploads the range again).  Where the library kept those bytes the
+                // comparison is exact and touches only the chunk this call was handed; otherwise the fingerprint reads the
+                // registered range, which the contract keeps allocated while any thread is inside align_hip on it — and the
+                // epoch is read again behind it: a release that raced with the read sends the call down the locked path
+                (last.shadow ? memcmp(last.shadow->data() + (peq_host - last.range_host), peq_host, last.group_bytes * chunk_read_num) == 0
+                             : (range_fingerprint(last.range_host, last.range_bytes) == last.range_fp &&
+                                last.epoch == g_range_epoch.load(std::memory_order_acquire)))) {
                 const size_t esz = result_elem_size(params.algo);
                 memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
                        last.scores->p + (peq_host - last.range_host) / last.group_bytes * HIP_V_NUM * esz,
@@ -1759,6 +1790,7 @@ void align_hip(char *ref, hip_read_t *read, int ref_len, int read_len, int word_
                 last.query.assign(ref, ref + ref_len);
                 last.scores = row;
                 last.range_fp = r->fp;
+                last.shadow = r->shadow;
                 turn.unlock();   // the copy needs no lock: the row is shared, immutable
                 memcpy(reinterpret_cast<char *>(results) + static_cast<size_t>(result_index) * HIP_V_NUM * esz,
                        row->p + first_group * HIP_V_NUM * esz, static_cast<size_t>(chunk_read_num) * HIP_V_NUM * esz);

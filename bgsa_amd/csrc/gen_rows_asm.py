@@ -36,6 +36,21 @@ MYERS_NW = [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25]  # Peq m
 # resident Peq masks with 9 registers per word (rows_ir.myers_parked_body): 26 and 28 words (801..896 bp) fit 256 VGPRs at all,
 # 18 words (545..576 bp) drop from 183 to 165 VGPRs = three waves per SIMD instead of two
 MYERS_PARKED_NW = [18, 26, 28]
+# 30 and 32 words (897..1024 bp) with the Peq planes resident (round 5): the two carry chains take turns over blocks of
+# MYERS_SPLIT words (rows_ir.myers_body(split=K)), so a row holds 2K temporaries instead of 2*nw: 7*nw + 2K + the kernel's own
+# registers <= 256.  Until then these widths ran on the code planes (nine instructions per word).
+MYERS_SPLIT_NW = [30, 32]
+MYERS_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_SPLIT", "8"))
+MYERS_PARK = os.environ.get("BGSA_GEN_MYERS_PARK", "sgpr")     # where the pausing chain waits: a scalar pair, or "vgpr" (two more VALU per switch)
+# "gap,window" of rows_ir.schedule_ilp for the Myers global bodies ("0" = the bodies as written: every instruction behind the one it reads from)
+MYERS_ILP = tuple(int(x) for x in os.environ.get("BGSA_GEN_MYERS_ILP", "0").split(","))
+
+
+def ilp(body: R.Body) -> R.Body:
+    return R.schedule_ilp(body, MYERS_ILP[0], MYERS_ILP[1]) if MYERS_ILP[0] > 0 else body
+
+
+MYERS_PLANES_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_PLANES_SPLIT", "0"))   # A/B: the code-plane rows of 30 / 32 words with the chains in turns
 MYERS_PEQ_BLOCK_NW = [12, 14, 16, 18, 20]  # column blocks with resident Peq planes (20 words: 238 VGPRs; 22 would need 256)
 MYERS_PAIR_NW = [1, 2]  # two rows per stream token: the 10-20 VALU row cannot hide the scalar dispatch
 MYERS_PLANES_NW = [10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]  # at most one padding word
@@ -52,6 +67,7 @@ S_BASE_LO, S_BASE_HI = "s64", "s65"
 S_PC, S_PC_LO, S_PC_HI = "s[66:67]", "s66", "s67"
 S_C = "s68"
 S_PTR, S_PTR_LO, S_PTR_HI = "s[70:71]", "s70", "s71"
+S_PARK = ["s[72:73]", "s[74:75]"]   # carry chains parked between their turns (rows_ir: SAVECC / LOADCC), clobbered by the loops that use them
 S_LEFT = "s69"  # windows this stream may still fetch; handed back to the caller: >= 0 after a well-formed stream,
                 # -1 = the budget ran out before END, -2 = a byte that is no stream code (L_fail slots)
 CLOBBERS = ["s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
@@ -124,6 +140,8 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
                 return f"%[e{c}_{name[1:]}]"
             if name.startswith("B"):
                 return f"%[b{name[1:]}]"
+            if name.startswith("$c"):
+                return S_PARK[int(name[2:])]
             return f"%[t{slot_of[name]}]"
         return reg
 
@@ -179,10 +197,11 @@ def gen_function(fn_name: str, template_args: str, body: R.Body, n_state: int, n
         masks_param = f"const uint32_t (&P)[5][{n_eq}]"
     ins.append('[qp] "s"(stream)')
     ins.append('[nwin] "s"(n_windows)')
-    clob = ", ".join(f'"{c}"' for c in CLOBBERS)
-    nops = sum(line.startswith("s_nop") for line in body.emit_asm(lambda x: x, 0))
+    parks = ["s72", "s73", "s74", "s75"] if any(op.kind in ("savecc", "loadcc") for op in body.ops) else []
+    clob = ", ".join(f'"{c}"' for c in CLOBBERS[:-3] + parks + CLOBBERS[-3:])
+    nops = sum(line.startswith("s_nop") for line in body.emit_asm(lambda x: S_PARK[int(x[2:])] if x.startswith("$c") else x, 0))
     return f"""
-// {body.valu_count()} VALU per row, {n_slots} temporaries, {nops} hazard nops
+// {body.valu_count()} VALU per row, {n_slots} temporaries, {nops} hazard nops{f", {body.salu_count()} scalar moves of VCC" if parks else ""}
 template <>
 __device__ __forceinline__ int {fn_name}<{template_args}>(uint32_t (&state)[{n_state}],
                                                    {masks_param},
@@ -1460,9 +1479,11 @@ def main() -> int:
              "                                               const unsigned long long stream, const int n_windows);\n"]
     for nw in MYERS_NW:  # G = 1 only: two groups per wave measured slower (fewer waves per SIMD)
         if nw not in MYERS_PARKED_NW:
-            parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_body(nw, 1), 2 * nw, nw))
+            parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1)), 2 * nw, nw))
     for nw in MYERS_PARKED_NW:  # 9 registers per word: HN parked in the VP register
-        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", R.myers_parked_body(nw), 2 * nw, nw))
+        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_parked_body(nw)), 2 * nw, nw))
+    for nw in MYERS_SPLIT_NW:   # the chains in turns over blocks of MYERS_SPLIT words: 7 registers per word + 2 * MYERS_SPLIT
+        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1, split=MYERS_SPLIT, park=MYERS_PARK)), 2 * nw, nw))
     parts.append("\n// Short subjects: the row is so short that the scalar dispatch bounds the loop, so a stream token\n"
                  "// carries two rows (bgsa_common.h: pair_stream_window).\n"
                  "// G = 2: two subject groups per wave — twice the vector work behind every dispatch, and these bodies are so\n"
@@ -1488,7 +1509,8 @@ def main() -> int:
                  "                                                      const uint32_t (&B)[3 * NW],\n"
                  "                                                      const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PLANES_NW:
-        parts.append(gen_function("myers_planes_rows_asm", f"{nw}", R.myers_planes_body(nw), 2 * nw, 0, n_planes=3 * nw))
+        parts.append(gen_function("myers_planes_rows_asm", f"{nw}", ilp(R.myers_planes_body(nw, MYERS_PLANES_SPLIT if nw >= 30 else 0)),
+                                  2 * nw, 0, n_planes=3 * nw))
     parts.append("\n// Semi-global on the code planes (subjects of 769..1024 bp): rows_ir.py: myers_semi_planes_body — the unused low\n"
                  "// columns carry code 7, which matches every class; 9 VALU per word + 3 per row.\n"
                  "template <int NW>\n"

@@ -328,8 +328,13 @@ __global__ __launch_bounds__(256) void myers_semi_asm_kernel(
 // character-code planes once per task (B0 = C|T, B1 = G|T, B2 = N) and the row body rebuilds the
 // match mask of its class with one v_bitop3 per word (rows_ir.py:myers_planes_body): 9 VALU per
 // word, 7*NW+1 registers, two waves per SIMD at NW = 32.
+#ifdef BGSA_PLANES_WAVES_PER_EU   // measurement builds (scripts/build_variant.sh ... EXTRA=-DBGSA_PLANES_WAVES_PER_EU=3): ask for an occupancy
+#define BGSA_PLANES_OCCUPANCY __attribute__((amdgpu_waves_per_eu(BGSA_PLANES_WAVES_PER_EU, BGSA_PLANES_WAVES_PER_EU)))
+#else
+#define BGSA_PLANES_OCCUPANCY
+#endif
 template <int NW, bool DYN = false>
-__global__ __launch_bounds__(256) void myers_global_planes_kernel(
+__global__ __launch_bounds__(256) BGSA_PLANES_OCCUPANCY void myers_global_planes_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
     int16_t *__restrict__ out, int ref_len, int read_len, long long ld, int n_groups, int word_num,
     int n_queries, int q_tile, int stream_stride_bytes, unsigned *__restrict__ fault_word,
@@ -644,7 +649,10 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
 {
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
-    const TaskPlan plan = plan_tasks(nq, (n_groups + G - 1) / G, static_cast<long long>(ref_len) * NW * G, 32, NW <= 8);   // the widths with registers to spare have a counter instantiation
+    // the widths with registers to spare have a counter instantiation, and so have the split-chain widths (30, 32 words: two
+    // waves per SIMD with or without the task loop's registers; their tasks are long, so at most 8 queries each, as on the code planes)
+    constexpr bool kCounter = NW <= 8 || NW >= 30;
+    const TaskPlan plan = plan_tasks(nq, (n_groups + G - 1) / G, static_cast<long long>(ref_len) * NW * G, NW >= 30 ? 8 : 32, kCounter);
     const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
@@ -660,7 +668,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
         const long long blocks = static_cast<long long>(grid.x) * grid.y;
         counter = task_counter_in(d_workspace, static_cast<size_t>(stride) * nq);
         int resident = persistent_blocks();
-        if constexpr (NW <= 8) resident = persistent_blocks_for(myers_global_asm_kernel<NW, G, true>, myers_lds_pad());
+        if constexpr (kCounter) resident = persistent_blocks_for(myers_global_asm_kernel<NW, G, true>, myers_lds_pad());
         grid = dim3(static_cast<unsigned>(blocks < resident ? blocks : resident), 1u);
     }
     if (int rc = kPairs ? launch_pack_query_pairs(d_content, ref_len, ref_start, ref_end, d_workspace, stream, counter)
@@ -668,7 +676,7 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
         return rc;
     unsigned *fault = nullptr;
     if (int rc = stream_guard(d_workspace, stride, kPairs ? kPairRefill : kCodeRefill, kPairs ? -1 : 7, stream, &fault)) return rc;
-    if constexpr (NW <= 8) {   // the widths with registers to spare have a dynamic instantiation
+    if constexpr (kCounter) {
         if (counter) {
             hipLaunchKernelGGL((myers_global_asm_kernel<NW, G, true>), grid, dim3(256), myers_lds_pad(), stream,
                                static_cast<const unsigned char *>(d_workspace), d_peq, d_results, ref_len,
@@ -863,13 +871,13 @@ int myers_max_plain_words()
 }
 
 // Widest subject (words) that keeps its five Peq planes in registers (8 VALU per word); wider ones use
-// the 3-bit code planes (11 per word, fewer registers).  BGSA_MYERS_PEQ_MAX_WORDS overrides (measurement).
+// the 3-bit code planes (9 per word, fewer registers).  BGSA_MYERS_PEQ_MAX_WORDS overrides (measurement).
 int myers_peq_max_words()
 {
     static const int limit = [] {
         const char *e = getenv("BGSA_MYERS_PEQ_MAX_WORDS");
         const int v = e ? atoi(e) : kPeqMaxWords;
-        return (v >= 8 && v <= 28) ? v : kPeqMaxWords;
+        return (v >= 8 && v <= 32) ? v : kPeqMaxWords;
     }();
     return limit;
 }
@@ -888,7 +896,7 @@ int pick_semi_planes_nw(int word_num)
 int pick_peq_nw(int word_num)
 {
     if (word_num > myers_peq_max_words()) return -1;
-    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25, 26, 28})
+    for (int nw : {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 25, 26, 28, 30, 32})
         if (nw >= word_num) return nw;
     return -1;
 }
@@ -1041,7 +1049,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
             BGSA_ASM_CASE(1) BGSA_ASM_CASE(2) BGSA_ASM_CASE(3) BGSA_ASM_CASE(4) BGSA_ASM_CASE(5)
             BGSA_ASM_CASE(6) BGSA_ASM_CASE(7) BGSA_ASM_CASE(8) BGSA_ASM_CASE(10) BGSA_ASM_CASE(12)
             BGSA_ASM_CASE(14) BGSA_ASM_CASE(16) BGSA_ASM_CASE(18) BGSA_ASM_CASE(20) BGSA_ASM_CASE(22)
-            BGSA_ASM_CASE(24) BGSA_ASM_CASE(25) BGSA_ASM_CASE(26) BGSA_ASM_CASE(28)
+            BGSA_ASM_CASE(24) BGSA_ASM_CASE(25) BGSA_ASM_CASE(26) BGSA_ASM_CASE(28) BGSA_ASM_CASE(30) BGSA_ASM_CASE(32)
 #undef BGSA_ASM_CASE
         default: break;
         }

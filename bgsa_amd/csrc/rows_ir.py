@@ -77,6 +77,16 @@ class Body:
     def ADD_CO(self, d, a, b): return self._emit("add_co", d, a, b)   # d = a + b, VCC = carry out
     def ADDC(self, d, a, b): return self._emit("addc", d, a, b)       # d = a + b + VCC, VCC = carry out
     def SETC1(self): return self._emit("setc1", "")                    # VCC = all ones (carry-in 1)
+    # A wave has ONE fast carry register (VCC; the VOP3 forms with an SGPR-pair carry are slow class).  A chain is parked in a
+    # scalar pair '$c<n>' and taken up again later (s_mov_b64: scalar pipe, no VALU issue slot) — what lets two chains run
+    # over the words in turns instead of one after the other (myers_body(split=K)).
+    def SAVECC(self, slot): return self._emit("savecc", f"$c{slot}")    # $c<slot> = VCC
+    def LOADCC(self, slot): return self._emit("loadcc", "", f"$c{slot}")  # VCC = $c<slot>
+    # The same through a VECTOR register, two fast-class VALU instructions instead of two scalar moves that wait for the vector
+    # pipe: d = 0 - VCC (v_subb_co_u32 d, vcc, d, d, vcc: all ones where the carry is set; d's old value cancels), and
+    # VCC = carry of d + d (v_add_co_u32 d, vcc, d, d; d is dead afterwards).
+    def SAVEV(self, d): return self._emit("savev", d)                    # d = VCC ? ~0 : 0   (VCC left undefined)
+    def LOADV(self, d): return self._emit("loadv", d, d)                 # VCC = d's top bit  (d clobbered)
 
     def ADDCZ(self, d): return self._emit("addcz", d, d)              # d = d + VCC  (v_addc_co_u32 d, vcc, 0, d, vcc)
     def SUBBZ(self, d): return self._emit("subbz", d, d)              # d = d - VCC  (v_subbrev_co_u32 d, vcc, 0, d, vcc)
@@ -138,7 +148,10 @@ class Body:
         return slot_of, n_slots
 
     def valu_count(self) -> int:
-        return sum(op.kind != "setc1" for op in self.ops)
+        return sum(op.kind not in ("setc1", "savecc", "loadcc") for op in self.ops)
+
+    def salu_count(self) -> int:
+        return sum(op.kind in ("setc1", "savecc", "loadcc") for op in self.ops)
 
     # ---- numpy interpreter --------------------------------------------------------------------
     def simulate(self, state: list, eq: list, cls: int = 0, planes: list | None = None,
@@ -149,6 +162,7 @@ class Body:
         regs: dict[str, np.ndarray] = {}
         fixed = {} if fixed is None else fixed
         vcc = np.zeros_like(state[0], dtype=bool)
+        parked: dict[str, np.ndarray] = {}     # carry chains parked in scalar pairs (savecc / loadcc)
 
         def rd(name):
             if name.startswith("S"):
@@ -177,6 +191,21 @@ class Body:
             k = op.kind
             if k == "setc1":
                 vcc = np.ones_like(vcc)
+                continue
+            if k == "savecc":
+                parked[op.dst] = vcc.copy()
+                continue
+            if k == "loadcc":
+                vcc = parked[op.srcs[0]].copy()
+                continue
+            if k == "savev":
+                wr(op.dst, np.where(vcc, FULL, np.uint32(0)))
+                vcc = vcc.copy()      # the borrow out of d - d - VCC equals VCC: the chain's carry survives, nothing relies on it
+                continue
+            if k == "loadv":
+                d = rd(op.srcs[0])
+                vcc = (d >> np.uint32(31)) != 0
+                wr(op.dst, (d.astype(np.uint64) * np.uint64(2)) & np.uint64(0xFFFFFFFF))
                 continue
             s = [rd(x) for x in op.srcs]
             if k == "and": wr(op.dst, s[0] & s[1])
@@ -236,6 +265,26 @@ class Body:
                 lines.append("s_mov_b64 vcc, -1")
                 since_vcc_write = 0
                 continue
+            if k == "savecc":      # a scalar read of VCC behind the VALU write: interlocked by the hardware
+                lines.append(f"s_mov_b64 {reg_name(op.dst)}, vcc")
+                since_vcc_write += 1
+                continue
+            if k == "loadcc":      # treated like setc1: its reader keeps two instructions' distance
+                lines.append(f"s_mov_b64 vcc, {reg_name(op.srcs[0])}")
+                since_vcc_write = 0
+                continue
+            if k == "savev":       # a VALU read of VCC: the chain link's two wait states
+                if since_vcc_write < 2:
+                    lines.append(f"s_nop {1 - since_vcc_write}")
+                d = reg_name(op.dst)
+                lines.append(f"v_subb_co_u32 {d}, vcc, {d}, {d}, vcc")
+                since_vcc_write = 0
+                continue
+            if k == "loadv":
+                d = reg_name(op.dst)
+                lines.append(f"v_add_co_u32 {d}, vcc, {d}, {d}")
+                since_vcc_write = 0
+                continue
             r = [reg_name(x) for x in op.srcs]
             d = reg_name(op.dst)
             if k in ("addc", "addcz", "subbz") and since_vcc_write < 2:
@@ -272,13 +321,19 @@ def count_hazard_nops(body: "Body") -> int:
     """s_nop padding emit_asm() would insert: addc issued fewer than 2 instructions after a VCC write."""
     nops, since = 0, 99
     for op in body.ops:
-        if op.kind == "setc1":
+        if op.kind in ("setc1", "loadcc"):
             since = 0
             continue
-        if op.kind in ("addc", "addcz", "subbz") and since < 2:
+        if op.kind == "savecc":
+            since += 1
+            continue
+        if op.kind == "loadv":
+            since = 0
+            continue
+        if op.kind in ("addc", "addcz", "subbz", "savev") and since < 2:
             nops += 1
             since = 2
-        since = 0 if op.kind in ("add_co", "addc", "addcz", "subbz") else since + 1
+        since = 0 if op.kind in ("add_co", "addc", "addcz", "subbz", "savev") else since + 1
     return nops
 
 
@@ -299,9 +354,9 @@ def schedule(body: "Body", window: int = 48) -> "Body":
     for i, op in enumerate(ops):
         reads = [r for r in op.srcs if r]
         writes = [w for w in (op.dst, op.dst2) if w]
-        if op.kind in ("addc", "addcz", "subbz"):
+        if op.kind in ("addc", "addcz", "subbz", "savecc", "savev"):
             reads.append("VCC")
-        if op.kind in ("add_co", "addc", "setc1", "addcz", "subbz"):
+        if op.kind in ("add_co", "addc", "setc1", "addcz", "subbz", "loadcc", "savev", "loadv"):
             writes.append("VCC")
         for r in reads:
             if r in last_write:
@@ -353,6 +408,109 @@ def schedule(body: "Body", window: int = 48) -> "Body":
     return out
 
 
+def _dependencies(ops):
+    """Per op the (predecessor, kind) pairs of a straight-line op list: 'raw' = reads what the predecessor wrote (a true
+    dependency: the value has to exist), 'vcc' = the same through the carry register, 'order' = write-after-read /
+    write-after-write (only the order matters)."""
+    last_write: dict = {}
+    readers: dict = {}
+    deps = [[] for _ in ops]
+    for i, op in enumerate(ops):
+        reads = [(r, "raw") for r in op.srcs if r]
+        writes = [w for w in (op.dst, op.dst2) if w]
+        if op.kind in ("addc", "addcz", "subbz", "savecc", "savev"):
+            reads.append(("VCC", "vcc"))
+        if op.kind in ("add_co", "addc", "setc1", "addcz", "subbz", "loadcc", "savev", "loadv"):
+            writes.append("VCC")
+        if op.kind == "savev":
+            reads = [x for x in reads if x[1] == "vcc"]      # d's old value cancels: not a dependency
+        for r, kind in reads:
+            if r in last_write:
+                deps[i].append((last_write[r], kind))
+        for w in writes:
+            if w in last_write:
+                deps[i].append((last_write[w], "order"))
+            deps[i] += [(j, "order") for j in readers.get(w, ()) if j != i]
+        for r, _ in reads:
+            readers.setdefault(r, []).append(i)
+        for w in writes:
+            last_write[w] = i
+            readers[w] = []
+    return deps
+
+
+def schedule_ilp(body: "Body", gap: int = 1, window: int = 24) -> "Body":
+    """List-schedule a straight-line body so that no instruction issues right behind the one whose result it reads.
+
+    Why (round 5): the Myers rows are, as written, ONE dependent chain — a = VP & E feeds the add, the add feeds HN, HN feeds M2,
+    M2 feeds HP — and a gfx950 SIMD issues a wave's dependent instruction later than an independent one.  With eight waves per
+    SIMD the other waves fill the slots; at two waves (the 1000 bp kernels: 228-253 VGPRs) they cannot, and every scalar
+    instruction or wait in the loop shows in the time (0.877 of the issue peak against 0.93-0.98 at 150 bp).  Here every true
+    dependency keeps `gap` other instructions between producer and consumer where the body has independent work to put there;
+    carry links keep the two the hardware demands (VALU writes VCC -> VALU reads VCC: 2 wait states); a chain parked by SAVECC
+    (a scalar read of VCC) waits `gap` + 1.  Among the instructions that may issue, the one with the longest dependent path
+    behind it goes first (the carry chains are the critical path); `window` bounds how far ahead of the oldest unscheduled
+    instruction one may be taken from — it trades stalls against live temporaries."""
+    ops = body.ops
+    n = len(ops)
+    deps = _dependencies(ops)
+    need = {"raw": gap + 1, "vcc": 3, "order": 1}
+    succs = [[] for _ in range(n)]
+    for i in range(n):
+        for p_, _ in deps[i]:
+            succs[p_].append(i)
+    height = [1] * n
+    for i in range(n - 1, -1, -1):
+        for s_ in succs[i]:
+            height[i] = max(height[i], 1 + height[s_])
+    remaining = [len({p_ for p_, _ in deps[i]}) for i in range(n)]
+    pos = [None] * n
+    ready = [i for i in range(n) if remaining[i] == 0]
+    order = []
+    oldest = 0
+    done = [False] * n
+    while len(order) < n:
+        while oldest < n and done[oldest]:
+            oldest += 1
+        here = len(order)
+
+        def earliest(i):
+            t = 0
+            for p_, kind in deps[i]:
+                d = need[kind] + (gap if ops[i].kind == "savecc" and kind == "vcc" else 0) - (1 if ops[i].kind == "savecc" and kind == "vcc" else 0)
+                t = max(t, pos[p_] + d)
+            return t
+
+        cands = [i for i in ready if i < oldest + window] or [min(ready)]
+        free = [i for i in cands if earliest(i) <= here]
+        if free:
+            pick = max(free, key=lambda i: (height[i], -i))
+        else:
+            pick = min(cands, key=lambda i: (earliest(i), -height[i], i))
+        ready.remove(pick)
+        done[pick] = True
+        pos[pick] = here
+        order.append(pick)
+        for s_ in set(succs[pick]):
+            remaining[s_] -= 1
+            if remaining[s_] == 0:
+                ready.append(s_)
+    out = Body()
+    out.ops = [ops[i] for i in order]
+    return out
+
+
+def dependent_pairs(body: "Body") -> int:
+    """How many instructions read a register the instruction right before them wrote (VALU results only)."""
+    n = 0
+    for prev, op in zip(body.ops, body.ops[1:]):
+        if prev.kind in ("setc1", "savecc", "loadcc") or op.kind in ("setc1", "savecc", "loadcc"):
+            continue
+        if prev.dst and prev.dst in op.srcs:
+            n += 1
+    return n
+
+
 # =================================================================================================
 # Myers unit-cost global (reference original/BGSA_CPU/align_core.c:65-132)
 # =================================================================================================
@@ -360,7 +518,7 @@ def schedule(body: "Body", window: int = 48) -> "Body":
 MYERS_EIGHT = __import__('os').environ.get('BGSA_GEN_MYERS_EIGHT', '1') != '0'   # '0': the 10-instruction rows of rounds 1-3 (A/B builds)
 
 
-def myers_body(nw: int, groups: int = 1) -> Body:
+def myers_body(nw: int, groups: int = 1, split: int = 0, park: str = "sgpr") -> Body:
     """State layout: S[(g*nw + w)*2 + 0] = VP word w of group g, +1 = VN.  E[g*nw + w] = match mask.
 
     Per word EIGHT instructions and two carry chains (round 4; ten and three until then: myers_body10).  In the terms of the
@@ -371,7 +529,16 @@ def myers_body(nw: int, groups: int = 1) -> Body:
     the adder already moved up one column, across the words.  What the classical order pays for (HN and its shift) is gone:
         a = VP & E ; s = VP + a (chain, carry-in 0) ; HNs = s ^ VP ^ a ; M2 = E | VN | HNs ; HP = VN | ~(M2 | VP)
         HPs = HP << 1 (chain, carry-in 1: the row edge) ; VN' = M2 & HPs ; VP' = (M2 & HNs) | ~(M2 | HPs)
-    (reference: 24 ops per 31-bit word, align_core.c:72-103).  Two temporaries per word: HP is formed in the dead VP register."""
+    (reference: 24 ops per 31-bit word, align_core.c:72-103).  Two temporaries per word: HP is formed in the dead VP register.
+
+    split = K > 0 (round 5): the two chains take turns over blocks of K words instead of running over all the words one after
+    the other — phase A of words 0..K-1, phase B of the same words, phase A of K..2K-1, ... — with the chain that pauses parked
+    in a scalar pair (SAVECC / LOADCC, scalar pipe).  The two temporaries of a word then live for one block, not for the row:
+    2K temporaries instead of 2*nw, which is what lets 30 and 32 words keep their five Peq planes resident (7*nw + 2K + the
+    kernel's own registers <= 256) where they ran on the code planes, nine instructions per word, before.
+    park = "vgpr": the pausing chain waits in a vector register (SAVEV / LOADV: one fast-class VALU instruction each, two more
+    temporaries) instead of a scalar pair — a scalar move of VCC waits for the vector pipe to drain, and at two waves per
+    SIMD nobody fills the gap."""
     if not MYERS_EIGHT:
         return myers_body10(nw, groups)
     b = Body()
@@ -381,18 +548,39 @@ def myers_body(nw: int, groups: int = 1) -> Body:
         E = lambda w: f"E{g * nw + w}"
         A = lambda w: f"a{g}_{w}"      # VP & E, then [v_in = 2]
         M = lambda w: f"m{g}_{w}"      # the sum, then M2
-        for w in range(nw):  # phase A: the addition's carry chain
-            b.AND(A(w), VP(w), E(w))
-            (b.ADD_CO if w == 0 else b.ADDC)(M(w), VP(w), A(w))
-            if w == nw - 1:
-                b.SETC1()    # the row edge D[i][0] - D[i-1][0] = +1 enters HP at bit 0 of word 0; three instructions ahead of its reader
-            b.BITOP3(A(w), M(w), VP(w), A(w), lambda s_, vp, a: s_ ^ vp ^ a)
-            b.BITOP3(M(w), E(w), VN(w), A(w), lambda e, vn, hn: e | vn | hn)
-            b.BITOP3(VP(w), M(w), VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
-        for w in range(nw):  # phase B: HP << 1 across words, then the new deltas
-            b.ADDC(VP(w), VP(w), VP(w))
-            b.AND(VN(w), M(w), VP(w))
-            b.BITOP3(VP(w), M(w), A(w), VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        blocks = [(0, nw)] if split <= 0 else [(lo, min(nw, lo + split)) for lo in range(0, nw, split)]
+        vg = park == "vgpr"
+        save = (lambda slot: b.SAVEV(f"cv{g}_{slot}")) if vg else b.SAVECC
+        load = (lambda slot: b.LOADV(f"cv{g}_{slot}")) if vg else b.LOADCC
+        for j, (lo, hi) in enumerate(blocks):
+            first, last = j == 0, j == len(blocks) - 1
+            for w in range(lo, hi):  # phase A: the addition's carry chain
+                b.AND(A(w), VP(w), E(w))
+                (b.ADD_CO if w == 0 else b.ADDC)(M(w), VP(w), A(w))
+                if w == hi - 1 and not last and not vg:
+                    save(0)
+                b.BITOP3(A(w), M(w), VP(w), A(w), lambda s_, vp, a: s_ ^ vp ^ a)
+                if w == hi - 1 and not vg:
+                    # the other chain's carry, two instructions ahead of its reader; block 0: the row edge D[i][0] - D[i-1][0] = +1
+                    # enters HP at bit 0 of word 0
+                    b.SETC1() if first else load(1)
+                b.BITOP3(M(w), E(w), VN(w), A(w), lambda e, vn, hn: e | vn | hn)
+                if w == hi - 1 and not last and vg:
+                    save(0)          # a VALU read of VCC: two instructions behind the link that wrote it
+                b.BITOP3(VP(w), M(w), VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+                if w == hi - 1 and vg:
+                    b.SETC1() if first else load(1)     # (as written its reader follows at once: schedule_ilp, or the emitter's s_nop, spaces them)
+            for w in range(lo, hi):  # phase B: HP << 1 across words, then the new deltas
+                b.ADDC(VP(w), VP(w), VP(w))
+                if w == hi - 1 and not last and not vg:
+                    save(1)
+                b.AND(VN(w), M(w), VP(w))
+                if w == hi - 1 and not last and not vg:
+                    load(0)
+                b.BITOP3(VP(w), M(w), A(w), VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+                if w == hi - 1 and not last and vg:
+                    save(1)
+                    load(0)
     return b
 
 
@@ -563,29 +751,41 @@ def myers_semi_simulate(subjects: np.ndarray, query: np.ndarray, nw: int) -> np.
     return (-st[2 * nw + 1].astype(np.int64)).astype(np.int16)
 
 
-def myers_planes_body(nw: int) -> Body:
+def myers_planes_body(nw: int, split: int = 0) -> Body:
     """Myers for long subjects (769..1024 bp): the five Peq planes of a subject (5*nw registers)
     are replaced by its 3-bit character code planes B[w*3+i] (3*nw registers) and the match mask
     of the row's class is rebuilt per word with one v_bitop3 (MATCH3) — 11 instructions per word,
     7*nw+1 registers, which keeps 32 words (1024 bp) at two waves per SIMD.  State as myers_body.
+    split = K > 0: the chains in turns over blocks of K words (see myers_body): 5*nw + 2K + 1 registers.
     """
     if MYERS_EIGHT:      # myers_body's eight instructions + the match mask: 9 per word, the same 7*nw + 1 registers
         b = Body()
         VP = lambda w: f"S{w * 2}"
         VN = lambda w: f"S{w * 2 + 1}"
-        for w in range(nw):
-            b.MATCH3("e", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}")
-            b.AND(f"a{w}", VP(w), "e")
-            (b.ADD_CO if w == 0 else b.ADDC)(f"m{w}", VP(w), f"a{w}")
-            if w == nw - 1:
-                b.SETC1()
-            b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
-            b.BITOP3(f"m{w}", "e", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
-            b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
-        for w in range(nw):
-            b.ADDC(VP(w), VP(w), VP(w))
-            b.AND(VN(w), f"m{w}", VP(w))
-            b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        blocks = [(0, nw)] if split <= 0 else [(lo, min(nw, lo + split)) for lo in range(0, nw, split)]
+        for j, (lo, hi) in enumerate(blocks):
+            first, last = j == 0, j == len(blocks) - 1
+            for w in range(lo, hi):
+                b.MATCH3(f"e{w}", f"B{w * 3}", f"B{w * 3 + 1}", f"B{w * 3 + 2}")   # a name per word: no false dependency between the words' masks (the slots are reused)
+                b.AND(f"a{w}", VP(w), f"e{w}")
+                (b.ADD_CO if w == 0 else b.ADDC)(f"m{w}", VP(w), f"a{w}")
+                if w == hi - 1 and not last:
+                    b.SAVECC(0)
+                if w == nw - 1 and not split:
+                    b.SETC1()
+                b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
+                if w == hi - 1 and split:
+                    b.SETC1() if first else b.LOADCC(1)
+                b.BITOP3(f"m{w}", f"e{w}", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
+                b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+            for w in range(lo, hi):
+                b.ADDC(VP(w), VP(w), VP(w))
+                if w == hi - 1 and not last:
+                    b.SAVECC(1)
+                b.AND(VN(w), f"m{w}", VP(w))
+                if w == hi - 1 and not last:
+                    b.LOADCC(0)
+                b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
         return b
     b = Body()
     P = lambda w: f"S{w * 2}"

@@ -158,16 +158,25 @@ size_t bgsa_hip_group_words(int algo, int word_num, int k);
  * malloc_mem() hands out page-locked memory for large blocks, so every buffer of the reference's
  * pipeline (cal_cpu.c:206-267) moves at full PCIe rate. */
 int bgsa_hip_set_auto_resident(int on);
-/* A resident range rewritten behind the library's back.  The contract above asks the caller to say so; when it does
- * not (a memcpy of a saved bucket over the registered buffer, a host that fills Peq itself), the library still does
- * not score from the stale device copy in silence: every scoring call — hip_cal_align_score, and align_hip on its
- * locked and its lock-free path — fingerprints the host range (66 cache lines: first, last and a
- * golden-ratio sequence of positions between them) and uploads the range again when the fingerprint differs from the one taken at upload; cached rows of
- * the old content are dropped.  A rewrite that happens to leave all sampled lines unchanged (a few groups patched
- * in place) is only caught in strict mode — BGSA_HIP_STRICT_RESIDENT=1 in the environment or
- * bgsa_hip_set_strict_resident(1) — which keeps a host copy of what was uploaded and compares every byte of the
- * part a call uses (a debugging aid: align_hip then always takes its locked path).  bgsa_hip_stale_ranges() counts
- * the re-uploads either check caused.  (SURVEY 8(b) "Ownership"; BGSA_KNC/cal_mic.c:348-356.) */
+/* THE CONTRACT of a resident range: between the hip_handle_reads() / bgsa_hip_bucket_resident() call that registered it
+ * and its release, its host bytes change ONLY through those two calls, and the memory stays allocated while any thread is
+ * inside a scoring call on it (the reference's pipeline does both: cal_cpu.c:363-401 fills a bucket with
+ * cpu_handle_reads and frees it after its compute threads have joined).  The host range is the truth; the device copy
+ * is a cache of it.
+ * What the library does for a caller that breaks the contract (a memcpy of a saved bucket over the registered buffer, a
+ * host that patches Peq words in place):
+ *   - ranges up to 8 MiB (every range in strict mode): EXACT.  The library keeps the host bytes it uploaded and every
+ *     scoring call — hip_cal_align_score, and align_hip on its locked and its lock-free path — compares the bytes it is
+ *     about to use against them (memcmp, < 1 ms for a whole 8 MiB bucket); any difference uploads the range again and
+ *     drops the rows cached from the old content;
+ *   - larger ranges: BEST EFFORT.  Every scoring call fingerprints the range (66 cache lines: first, last and a
+ *     golden-ratio sequence of positions between them) and uploads it again when the fingerprint differs from the one
+ *     taken at upload.  A rewrite that leaves all sampled lines unchanged (a few groups patched in place) is not seen.
+ * bgsa_hip_set_strict_resident(1) / BGSA_HIP_STRICT_RESIDENT=1: the exact check for every range (costs a host copy of
+ * each bucket and a memcmp per call); (0): the default above; (-1) / BGSA_HIP_STRICT_RESIDENT=-1: the fingerprint alone
+ * (measurement).  Switching the mode re-uploads every range on its next use and drops the cached rows.
+ * bgsa_hip_stale_ranges() counts the re-uploads either check caused.  (SURVEY 8(b) "Ownership";
+ * BGSA_KNC/cal_mic.c:348-356.) */
 int bgsa_hip_set_strict_resident(int on);
 int bgsa_hip_stale_ranges(uint64_t *count);
 /* host_peq[0 .. bytes) holds whole groups in the library's own layout with word_num words. */

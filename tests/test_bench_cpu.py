@@ -112,3 +112,34 @@ def test_checksum_needs_no_int64_copy_of_the_matrix():
     bench = _bench()
     out = torch.randint(-150, 1, (1000, 130), dtype=torch.int16)
     assert bench.checksum_int64(out, 100, rows_per_block=64) == int(out[:, :100].to(torch.int64).sum())
+
+
+def test_utilisation_scalars_have_the_same_names_in_every_entry():
+    """The <= 1 roofline figure must survive a parser that keeps only the scalars of `roofline`: three flat keys, the same names in
+    the headline's roofline object and in each entry of other_configs (bench.flat_issued is what both call)."""
+    bench = _bench()
+    assert bench.ISSUED_SCALARS == ("issued_frac", "issued_frac_sustained", "valu_per_wave_row")
+    pmc_form = {"source": "SQ_INSTS_VALU, r05_cfg2_pmc.csv", "frac": 0.906, "frac_at_sustained_clock": 0.98, "valu_per_nominal_wave_row": 40.26}
+    flat = bench.flat_issued(pmc_form)
+    assert flat == {"issued_frac": 0.906, "issued_frac_sustained": 0.98, "valu_per_wave_row": 40.26, "issued_source": "SQ_INSTS_VALU, r05_cfg2_pmc.csv"}
+    gen_form = {"source": "generator instruction lists (rows_ir.py) x rows x waves", "frac": 0.9, "valu_per_row": 40}
+    assert bench.flat_issued(gen_form)["valu_per_wave_row"] == 40 and bench.flat_issued(gen_form)["issued_frac_sustained"] is None
+    assert set(bench.flat_issued(None)) == set(bench.ISSUED_SCALARS) | {"issued_source"} and not any(bench.flat_issued(None).values())
+    src = (ROOT / "bench.py").read_text()
+    assert src.count("**flat_issued(issued)") == 1 and "entry.update(flat_issued(entry[\"issued\"]))" in src
+
+
+def test_every_config_is_one_job_at_every_n():
+    """At N > 1 the headline is the SAME bucket cut by plan_shards, with the streamed gather inside the timed region: total work is
+    fixed as N grows, so every config says "strong" — and the watchdog's stub says the same as the measured line."""
+    import argparse
+    bench = _bench()
+    assert {cfg[6] for cfg in bench.CONFIGS.values()} == {"strong"}
+    assert bench.CONFIGS[2][2:5] == (10_000, 1_000_000, 150) and bench.CONFIGS[5][2:5] == (1_000, 1_000_000, 1000)
+    wd = bench.RunWatchdog(1, 4, argparse.Namespace(config=2, steps=3, warmup=1), limit=3600)
+    try:
+        stub = wd.stub()
+    finally:
+        wd.cancel()
+    assert stub["scaling"] == "strong" and stub["config"]["workload"] == bench.CONFIGS[2][1] and stub["n_gpus"] == 4
+    assert bench.GATHER_BLOCK_ROWS >= bench.REF_BUCKET_COUNT

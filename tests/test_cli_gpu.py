@@ -284,6 +284,70 @@ def test_reference_host_pipeline_other_query_blocks(tmp_path, oracle, binary, th
     assert "GCUPS" in report
 
 
+# ---- the COARSE seam as a drop-in ("where a device launch belongs"): the reference's main.c /
+# file.c / thread.c unmodified and its cal_cpu.c minus the definition of cpu_cal_align_score (examples/BGSA_HIP/derive_cal_hip.py,
+# applied at build time to the reference file where it lies) — cpu_cal's call lands in the library's hip_cal_align_score: one device
+# launch per block of REF_BUCKET_COUNT queries, no align_hip, no row cache (oracle/Makefile: _ref/original_hip_coarse) --------------
+REF_HIP_COARSE = ROOT / "oracle" / "_ref" / "original_hip_coarse"
+
+
+def _run_coarse_host(tmp_path, g, binary, threads=4, env_extra=None):
+    (tmp_path / "query.txt").write_bytes(B.rows_to_buffer(g["queries"]).tobytes())
+    (tmp_path / "subject.txt").write_bytes(B.rows_to_buffer(g["subjects"]).tobytes())
+    env = dict(os.environ, BGSA_HIP_SEAM_STATS="1", **(env_extra or {}))
+    p = subprocess.run([str(REF_HIP_COARSE / binary), "-q", "query.txt", "-d", "subject.txt", "-f", "result.txt", "-N", str(threads)],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    conv = ROOT / "oracle" / "_ref" / "original_cpu" / "convert"
+    subprocess.run([str(conv), "-r", "result.txt", "-o", "scores.txt"], cwd=tmp_path, check=True, capture_output=True)
+    flat = np.loadtxt(tmp_path / "scores.txt", dtype=np.int64, ndmin=1)
+    return flat.reshape(g["queries"].shape[0], g["subjects"].shape[0]), p.stdout + p.stderr
+
+
+def test_coarse_seam_binary_binds_the_grid_not_the_row():
+    """What the two drop-ins import from the library: the fine one align_hip (57,900 calls per 100-query block of 1M subjects,
+    served by the row cache), the coarse one hip_cal_align_score and nothing of the fine seam."""
+    if not (REF_HIP_COARSE / "aligner").exists():
+        pytest.skip("oracle/_ref/original_hip_coarse not built (needs /root/reference at build time)")
+    undefined = lambda path: {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--undefined-only", str(path)], capture_output=True,   # noqa: E731
+                                                                      text=True, check=True).stdout.splitlines() if ln.strip()}
+    coarse, fine = undefined(REF_HIP_COARSE / "aligner"), undefined(REF_HIP / "aligner")
+    assert {"hip_cal_align_score", "hip_handle_reads", "malloc_mem", "init_mapping_table"} <= coarse and "align_hip" not in coarse
+    assert {"align_hip", "hip_handle_reads"} <= fine and "hip_cal_align_score" not in fine
+
+
+@pytest.mark.parametrize("name,binary", [("f1_myers_150", "aligner"), ("f6_myers_ns100", "aligner"), ("f2_myers_1000", "aligner"),
+                                         ("f9_myers_140x150", "aligner"), ("f7_bitpal_150", "aligner_bitpal")])
+def test_reference_host_pipeline_through_the_coarse_seam(tmp_path, name, binary):
+    if not (REF_HIP_COARSE / binary).exists():
+        pytest.skip("oracle/_ref/original_hip_coarse not built (needs /root/reference at build time)")
+    g = load_golden(name)
+    got, report = _run_coarse_host(tmp_path, g, binary)
+    assert np.array_equal(got, g["scores"])          # the reference's scores, through its own host code, one launch per query block
+    assert "GCUPS" in report
+
+
+def test_coarse_and_fine_seam_binaries_agree_on_1k_x_1k(tmp_path, oracle):
+    """BASELINE configs[0]'s shape (1k x 1k x 150 bp) through both drop-ins: the same result file, and the coarse one gets there
+    with ten library calls (ten blocks of REF_BUCKET_COUNT = 100 queries) where the fine one makes thousands."""
+    if not (REF_HIP_COARSE / "aligner").exists() or not (REF_HIP / "aligner").exists():
+        pytest.skip("oracle/_ref drop-ins not built (need /root/reference at build time)")
+    q = oracle.gen_reads(0xB65A0001, 1000, 150)
+    s = oracle.gen_reads(0xB65A1001, 1000, 150)
+    s[:50] = oracle.mutate(q[np.arange(50) * 19 % 1000], np.arange(50) % 13, 7)
+    g = {"queries": q, "subjects": s}
+    (tmp_path / "c").mkdir()
+    (tmp_path / "f").mkdir()
+    coarse, rep_c = _run_coarse_host(tmp_path / "c", g, "aligner", threads=8)
+    fine, _ = _run_reference_host(tmp_path / "f", g, "aligner", threads=8)
+    assert np.array_equal(coarse, fine) and np.array_equal(coarse, oracle.myers64(q, s))
+    assert (tmp_path / "c" / "result.txt").read_bytes() == (tmp_path / "f" / "result.txt").read_bytes()
+    import re
+    m = re.search(r"seam calls (\d+)", rep_c) or re.search(r"calls[ =:]+(\d+)", rep_c)
+    if m:                                   # BGSA_HIP_SEAM_STATS=1: the library's own count of scoring calls
+        assert int(m.group(1)) == 10, rep_c[-600:]
+
+
 def test_reference_host_pipeline_other_scores(tmp_path, oracle):
     sets = [x for x in B.score_sets() if x != (2, -3, -5)]
     if not (REF_HIP / "aligner_bitpal").exists() or not sets:

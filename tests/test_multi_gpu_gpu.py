@@ -86,52 +86,75 @@ def _bench_two_ranks(extra_env, extra_args=(), want_rc=0, ranks=2):
 def test_bench_line_for_two_ranks(config):
     r = _bench_two_ranks({}, ("--config", str(config)) + (("--length", "200") if config == 5 else ()))
     assert r["n_gpus"] == 2 and r["value"] > 0
-    strong = config == 5
-    assert r["scaling"] == ("strong" if strong else "weak")
-    assert r["config"]["subjects_total"] == (64000 if strong else 128000)
-    assert r["config"]["subjects_this_rank"] == (32000 if strong else 64000)
+    # the job is the SAME bucket at every N, cut by plan_shards; the streamed gather is inside the timed region
+    assert r["scaling"] == "strong"
+    assert r["config"]["subjects_total"] == 64000 and r["config"]["subjects_this_rank"] == 32000
+    assert r["config"]["gather_block_rows"] == 1000 and "SIZE OVERRIDDEN" in r["config"]["workload"]
+    ko = r["kernel_only"]
+    assert ko["gcups"] > 0 and ko["ms_per_pass"] > 0
+    assert r["value"] <= ko["gcups"] * 1.02, (r["value"], ko)          # the gather cannot make the job faster than its kernels
     g = r["gather"]
     assert "error" not in g, g
-    assert g["root_blocks_checked"] >= 3 and g["gcups_with_gather"] > 0
+    assert g["block_rows"] == 1000 and g["blocks_per_step"] == 1 and g["bytes_to_root_per_step"] == 32000 * 300 * 2
+    assert g["root_blocks_received"] >= 3 + 1                          # warm-up + two steps + the content check's block
+    assert g["content_check"]["segments_ok"] is True and g["content_check"]["rows"] == 300
+    assert g["gcups_with_gather"] == r["value"]
+    small = r["gather_blocks_of_100"]
+    assert "error" not in small, small
+    assert small["root_blocks_received"] >= 3 and small["gcups_with_gather"] > 0 and small["bytes_to_root_per_block"] == 32000 * 100 * 2
     # rank 0 at N = 1 only — and the line says so instead of omitting the keys
     assert "skipped" in r["cpu_baseline"] and "skipped" in r["total_gcups"] and "skipped" in r["other_configs"]
     assert r["rccl_ok"] is None                    # gloo rehearsal: no RCCL byte moved, the line does not claim one did
     assert r["preflight"]["all_gather"]["content_ok"] is True and len(r["ranks"][1]["peer_access"]) >= 1
     if config == 2:
         # the default invocation at N > 1 also times BASELINE configs[4]: ONE bucket of 1000 bp reads cut by plan_shards
-        st = r["strong"]
+        st = r["config5_sharded"]
         assert "error" not in st, st
         assert st["scaling"] == "strong" and st["length_bp"] == 1000 and st["subjects_total"] == 64000
         assert [x["subjects"] for x in st["ranks"]] == [32000, 32000] and all(x["kernel_ms"] > 0 for x in st["ranks"])
         assert st["gcups"] > 0 and st["gather"]["gcups_with_gather"] > 0 and st["gather"]["root_blocks_checked"] >= 3
+        # ... and the weak-scaling figure of rounds 1-4 as a side key: a full bucket per rank, kernels only
+        wk = r["weak"]
+        assert "error" not in wk, wk
+        assert wk["scaling"] == "weak" and wk["subjects_per_rank"] == 64000 and wk["subjects_total"] == 128000 and wk["gcups"] > 0
     else:
-        assert "strong" not in r
+        assert "config5_sharded" not in r and "weak" not in r
     # the line proves that two ranks ran: gathered through the process group, one entry per rank with its own kernel time
     assert r["gather_ok"] is True
     assert [x["rank"] for x in r["ranks"]] == [0, 1] and r["ranks_seen"] == 2
     assert all(x["kernel_ms"] > 0 and x["device"] for x in r["ranks"]) and r["ranks"][0]["pid"] != r["ranks"][1]["pid"]
     assert r["config"]["kernel_source_id"] and len(r["config"]["kernel_source_id"]) == 16
+    assert all(name in r["roofline"] for name in ("issued_frac", "issued_frac_sustained", "valu_per_wave_row"))
 
 
-def test_bench_line_for_four_ranks_weak_and_strong():
-    """Four ranks on the one card (the most this box allows beside the test process): config 2's weak-scaling shape with three
-    peers streaming their tiles to rank 0, and the strong leg's plan_shards cut of ONE bucket into four slices."""
-    r = _bench_two_ranks({}, ("--config", "2"), ranks=4)
+def test_bench_line_for_four_ranks_one_bucket_in_four_slices():
+    """Four ranks on the one card (the most this box allows beside the test process): ONE 64,000-subject bucket cut by
+    plan_shards into four slices, three peers streaming their tiles to rank 0 inside the timed region, several blocks per step
+    (BGSA_BENCH_BLOCK_ROWS=100: three blocks of the 300 queries); the config-5 leg cuts its bucket the same way."""
+    r = _bench_two_ranks({"BGSA_BENCH_BLOCK_ROWS": "100"}, ("--config", "2"), ranks=4)
     assert r["n_gpus"] == 4 and r["ranks_seen"] == 4 and [x["rank"] for x in r["ranks"]] == [0, 1, 2, 3]
-    assert r["config"]["subjects_total"] == 4 * 64000 and r["gather_ok"] is True
-    assert r["gather"]["bytes_to_root_per_block"] == 3 * 64000 * 100 * 2
-    st = r["strong"]
+    assert r["scaling"] == "strong" and r["config"]["subjects_total"] == 64000 and r["gather_ok"] is True
+    assert [x["subjects"] for x in r["ranks"]] == [16000] * 4
+    assert r["value"] <= r["kernel_only"]["gcups"] * 1.02
+    g = r["gather"]
+    assert g["block_rows"] == 100 and g["blocks_per_step"] == 3 and g["bytes_to_root_per_block"] == 3 * 16000 * 100 * 2
+    assert g["root_blocks_received"] == 3 * 3 + 1 and g["content_check"]["segments_ok"] is True
+    assert "gather_blocks_of_100" not in r          # the timed region already ran the reference's block size
+    st = r["config5_sharded"]
     assert "error" not in st, st
     assert [x["subjects"] for x in st["ranks"]] == [16000] * 4 and st["subjects_total"] == 64000
     assert st["gather"]["bytes_to_root_per_block"] == 3 * 16000 * 100 * 2 and st["gather"]["root_blocks_checked"] >= 3
+    assert r["weak"]["subjects_total"] == 4 * 64000
 
 
 def test_bench_line_survives_a_gather_that_never_finishes():
-    """An interconnect problem is a hang, not an exception: the watchdog prints the kernel-only line, marked
-    gather_ok = false, and every rank leaves with a NON-ZERO exit code — a hung leg is not a clean run."""
+    """An interconnect problem is a hang, not an exception.  The gather is inside the timed region now, so a region that does
+    not finish leaves no value: the watchdog prints a line with value = null that carries the kernels-only figure measured
+    before it, gather_ok = false, and every rank leaves with a NON-ZERO exit code — a hung run is not a clean run."""
     r = _bench_two_ranks({"BGSA_BENCH_GATHER_TIMEOUT": "0.001"}, ("--config", "2"), want_rc=3)
-    assert r["n_gpus"] == 2 and r["value"] > 0
-    assert "did not finish" in r["gather"]["error"] and r["gather_ok"] is False
+    assert r["n_gpus"] == 2 and r["value"] is None and r["scaling"] == "strong"
+    assert r["kernel_only"]["gcups"] > 0
+    assert "did not finish" in r["gather"]["error"] and r["gather_ok"] is False and r["rccl_ok"] is False
 
 
 def test_bench_line_under_torchrun_with_one_rank_goes_through_rccl():

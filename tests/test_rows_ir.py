@@ -532,3 +532,56 @@ def test_myers_eight_instruction_row_equals_the_ten_instruction_row(nw, groups):
         new.simulate(b, eq)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), row
         assert all(not (b[2 * w] & b[2 * w + 1]).any() for w in range(nw * groups))      # the invariant survives
+
+
+# ---- round 5: the two carry chains in turns over blocks of K words (SAVECC / LOADCC), and the dependency-aware order ----
+@pytest.mark.parametrize("qlen,slen,nw,split", [(120, 1000, 32, 8), (60, 930, 30, 8), (200, 1024, 32, 4), (150, 150, 5, 2), (90, 257, 9, 3),
+                                                (40, 1000, 32, 12)])
+def test_myers_split_body_matches_oracle(oracle, qlen, slen, nw, split):
+    """myers_body(split=K): phase A and phase B of K words at a time, the pausing chain parked in a scalar pair — the form
+    that keeps five Peq planes resident at 30 / 32 words.  Against the oracle, with reads that drive the carries through
+    every word (homopolymers) and N columns."""
+    q = oracle.gen_reads(7100 + qlen, 2, qlen)
+    s = oracle.gen_reads(7200 + slen, 24, slen)
+    m = min(qlen, slen)
+    s[:8, :m] = oracle.mutate(q[np.arange(8) % 2][:, :m], np.arange(8) * 3, 7300)
+    s[3, : slen // 3] = ord("N")
+    s[9] = ord("A")
+    q[1] = ord("A")
+    want = oracle.myers64(q, s)
+    body = R.myers_body(nw, 1, split=split)
+    peq = R.build_peq32(s, nw)
+    for i in range(q.shape[0]):
+        st = R.myers_init_state(nw, 1, s.shape[0])
+        R.run_rows(body, st, peq, q[i])
+        assert np.array_equal(R.myers_score(st, nw, qlen, slen), want[i])
+    blocks = -(-nw // split)
+    assert body.valu_count() == 8 * nw and body.salu_count() == 4 * (blocks - 1) + 1
+    assert R.count_hazard_nops(body) == 0 and body.allocate_temps()[1] == 2 * min(split, nw)
+
+
+@pytest.mark.parametrize("make,nw,planes", [(lambda: R.myers_body(5), 5, False), (lambda: R.myers_body(3, groups=2), 6, False),
+                                             (lambda: R.myers_body(32, 1, split=8), 32, False),
+                                             (lambda: R.myers_planes_body(32), 32, True), (lambda: R.myers_planes_body(30, split=8), 30, True)])
+@pytest.mark.parametrize("gap,window", [(1, 12), (2, 24)])
+def test_schedule_ilp_keeps_the_function_and_separates_dependent_instructions(make, nw, planes, gap, window):
+    """rows_ir.schedule_ilp reorders a body so that no instruction issues right behind the one whose result it reads: the same
+    function of (state, masks) on random inputs for every class, no back-to-back dependent pair left, at most a few more
+    temporaries, no hazard padding the original did not need."""
+    rng = np.random.default_rng(nw * 100 + gap)
+    body = make()
+    sched = R.schedule_ilp(body, gap, window)
+    assert sorted((o.kind, o.dst, o.srcs) for o in body.ops) == sorted((o.kind, o.dst, o.srcs) for o in sched.ops)
+    for cls in range(5):
+        vp = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) for _ in range(nw)]
+        vn = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) & ~vp[w] for w in range(nw)]
+        eq = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) for _ in range(nw)]
+        pl = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) for _ in range(3 * nw)]
+        s1 = [x.copy() for w in range(nw) for x in (vp[w], vn[w])]
+        s2 = [x.copy() for x in s1]
+        body.simulate(s1, eq, cls, planes=pl if planes else None)
+        sched.simulate(s2, eq, cls, planes=pl if planes else None)
+        assert all(np.array_equal(a, b) for a, b in zip(s1, s2))
+    assert R.dependent_pairs(body) > nw and R.dependent_pairs(sched) == 0
+    assert sched.allocate_temps()[1] <= body.allocate_temps()[1] + 8
+    assert sched.valu_count() == body.valu_count() and sched.salu_count() == body.salu_count()
