@@ -109,8 +109,9 @@ def issued_valu_per_row(algo: int, wn: int, k: int = 0, scores=None):
         import rows_ir as R
     except Exception:
         return None
-    if algo == B.ALGO_MYERS and wn <= 28:      # Peq planes resident (myers_global_asm_kernel): 8 VALU per word at every width
-        nw = wn if wn <= 8 or wn == 25 else next(n for n in list(range(10, 25, 2)) + [26, 28] if n >= wn)
+    peq_max = int(os.environ.get("BGSA_MYERS_PEQ_MAX_WORDS", "32"))     # myers_global.hip: myers_peq_max_words()
+    if algo == B.ALGO_MYERS and wn <= min(peq_max, 32):      # Peq planes resident (myers_global_asm_kernel): 8 VALU per word at every width
+        nw = wn if wn <= 8 or wn == 25 else next(n for n in list(range(10, 25, 2)) + [26, 28, 30, 32] if n >= wn)
         return R.myers_body(nw).valu_count()
     if algo == B.ALGO_MYERS and wn <= 32:      # 3-bit code planes (myers_global_planes_kernel)
         nw = next(n for n in range(26, 33, 2) if n >= wn)
@@ -367,6 +368,64 @@ def total_gcups_leg(algo, k, scores, q_host, s_rows_dev, ns, ns_pad, length, dev
                     f"preprocess -> kernel -> D2H (double-buffered on a second stream) -> pinned host scores; "
                     f"formula of cal_cpu.c:473-474 without the file I/O",
             "h2d_bytes": int(h_rows.numel()), "d2h_bytes": int(nq * ns_pad * esz)}
+
+
+class PowerSampler:
+    """rocm-smi's power and shader clock sampled on the host while the timed region runs (a thread that starts `rocm-smi
+    --showpower --showclocks --json` about once a second: host work only, nothing is launched on the GPU).  The headline kernel is
+    power-bound (LABNOTES §9.5): the clock the chip holds under it — 2.2-2.3 of the nominal 2.4 GHz — is the box-to-box spread of
+    the headline number, and this puts the watts beside it.  Best effort: any failure leaves `None`."""
+
+    def __init__(self, period_s: float = 1.0):
+        self.period, self.samples, self._stop, self._thread = period_s, [], threading.Event(), None
+
+    def _once(self):
+        import re
+        import subprocess
+        try:
+            p = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+            cards = json.loads(p.stdout[p.stdout.index("{"):])
+        except Exception:
+            return None
+        out = {}
+        for card, kv in cards.items():
+            if not isinstance(kv, dict):
+                continue
+            for key, val in kv.items():
+                m = re.search(r"-?\d+(\.\d+)?", str(val))
+                if not m:
+                    continue
+                if re.search(r"power", key, re.I) and re.search(r"\(W\)|watt", key, re.I):
+                    out.setdefault("watts", []).append(float(m.group()))
+                elif re.search(r"sclk", key, re.I):
+                    out.setdefault("sclk_mhz", []).append(float(m.group()))
+        return out or None
+
+    def start(self):
+        def loop():
+            while not self._stop.is_set():
+                t0 = time.time()
+                one = self._once()
+                if one:
+                    self.samples.append(one)
+                self._stop.wait(max(0.05, self.period - (time.time() - t0)))
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=6)
+        if not self.samples:
+            return None
+        # one GPU box: the busiest card of every sample is the one under the kernel (others, if rocm-smi lists any, idle)
+        watts = [max(x["watts"]) for x in self.samples if x.get("watts")]
+        sclk = [max(x["sclk_mhz"]) for x in self.samples if x.get("sclk_mhz")]
+        return {"samples": len(self.samples), "watts_mean": round(float(np.mean(watts)), 1) if watts else None,
+                "watts_max": round(max(watts), 1) if watts else None,
+                "sclk_mhz_mean": round(float(np.mean(sclk)), 1) if sclk else None,
+                "source": "rocm-smi --showpower --showclocks --json, about once a second on the host while the timed region ran"}
 
 
 class RunWatchdog:
@@ -699,6 +758,7 @@ def main() -> int:
         return elapsed, float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) / 1e3
 
     clock_box = [None]
+    power = None
     one_launch = lambda: aligner.score(0, nq, out=out)     # noqa: E731  every query against the rank's resident subjects
     kernel_only = None
     gs = None
@@ -755,7 +815,9 @@ def main() -> int:
         probe_note = None
     else:
         wd.stage = "timed region"
+        sampler = PowerSampler().start() if (rank == 0 and os.environ.get("BGSA_BENCH_POWER", "1") != "0") else None
         elapsed, kernel_s = timed(one_launch, args.steps, args.warmup, probe=True)
+        power = sampler.stop() if sampler else None
         clock = clock_box[0]
         # The probes must not cost anything.  If the wall time of the timed region is not the kernels' time (events on the launch
         # stream) plus launch overhead, something held the launches back — the probes, on a box where they do not run beside the
@@ -889,6 +951,7 @@ def main() -> int:
             # N > 1: `value` includes the streamed gather; this is the kernels alone (one launch per pass, max over ranks)
             "kernel_only": kernel_only,
             "clock": clock if clock is not None else ({"sustained_mhz": None, "note": probe_note} if probe_note else None),
+            "power": power,
             "ranks_seen": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["device_index"], r["pid"]) for r in ranks_info}),
             "ranks": ranks_info,
             "gather_ok": None,
@@ -911,6 +974,8 @@ def main() -> int:
                 # the utilisation figures as scalars of this object (a parser that keeps only scalars keeps these): VALU instructions
                 # issued x 64 lanes / kernel time / peak, at the nominal and at the sustained clock; instructions per (query row, wave)
                 **flat_issued(issued),
+                "sustained_mhz": clock["sustained_mhz"] if clock else None,       # the clock the chip held under the timed kernels (probe waves)
+                "watts_mean": power["watts_mean"] if power else None,            # and the power it drew (rocm-smi, host-side sampling)
                 "issued": issued,
                 "traffic": traffic,
                 "traffic_source": pmc_src if (traffic or pmc is None) else None,

@@ -42,12 +42,21 @@ MYERS_PARKED_NW = [18, 26, 28]
 MYERS_SPLIT_NW = [30, 32]
 MYERS_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_SPLIT", "8"))
 MYERS_PARK = os.environ.get("BGSA_GEN_MYERS_PARK", "sgpr")     # where the pausing chain waits: a scalar pair, or "vgpr" (two more VALU per switch)
-# "gap,window" of rows_ir.schedule_ilp for the Myers global bodies ("0" = the bodies as written: every instruction behind the one it reads from)
-MYERS_ILP = tuple(int(x) for x in os.environ.get("BGSA_GEN_MYERS_ILP", "0").split(","))
+# "gap,window[,instructions from carry link to carry link]" of rows_ir.schedule_ilp for the Myers GLOBAL bodies with resident Peq planes
+# ("0" = the bodies as written: every instruction right behind the one it reads from).  Default 2,24 since round 5, same-box A/Bs in
+# profiles/r05_ilp_ab.txt, r05_balance_ab.txt: 1000 bp (32 words, chains in turns over 8) 4,205 -> 4,030 ms, 768 bp 1,212 -> 1,196, 512 bp
+# 488.6 -> 485.8, 150 bp 330.8 -> 329.2; a minimum link distance of 4 or 5 and the `balanced` phases measured no better.  The code-plane
+# bodies stay as written: scheduled they measured SLOWER (32 words: 4,164 -> 4,238 / 4,318 ms).
+MYERS_ILP = tuple(int(x) for x in os.environ.get("BGSA_GEN_MYERS_ILP", "2,24").split(","))
+MYERS_BALANCED = os.environ.get("BGSA_GEN_MYERS_BALANCED", "0") == "1"    # HP of word w + 1 formed in phase B: four instructions per carry link in both phases
 
 
 def ilp(body: R.Body) -> R.Body:
-    return R.schedule_ilp(body, MYERS_ILP[0], MYERS_ILP[1]) if MYERS_ILP[0] > 0 else body
+    return R.schedule_ilp(body, MYERS_ILP[0], MYERS_ILP[1], *MYERS_ILP[2:3]) if MYERS_ILP[0] > 0 else body
+
+
+def ilp_planes(body: R.Body) -> R.Body:      # BGSA_GEN_MYERS_ILP_PLANES=1: the measurement builds that schedule the code-plane bodies too
+    return ilp(body) if os.environ.get("BGSA_GEN_MYERS_ILP_PLANES", "0") == "1" else body
 
 
 MYERS_PLANES_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_PLANES_SPLIT", "0"))   # A/B: the code-plane rows of 30 / 32 words with the chains in turns
@@ -1479,11 +1488,11 @@ def main() -> int:
              "                                               const unsigned long long stream, const int n_windows);\n"]
     for nw in MYERS_NW:  # G = 1 only: two groups per wave measured slower (fewer waves per SIMD)
         if nw not in MYERS_PARKED_NW:
-            parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1)), 2 * nw, nw))
+            parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1, balanced=MYERS_BALANCED)), 2 * nw, nw))
     for nw in MYERS_PARKED_NW:  # 9 registers per word: HN parked in the VP register
-        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_parked_body(nw)), 2 * nw, nw))
+        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1, balanced=MYERS_BALANCED)), 2 * nw, nw))
     for nw in MYERS_SPLIT_NW:   # the chains in turns over blocks of MYERS_SPLIT words: 7 registers per word + 2 * MYERS_SPLIT
-        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1, split=MYERS_SPLIT, park=MYERS_PARK)), 2 * nw, nw))
+        parts.append(gen_function("myers_rows_asm", f"{nw}, 1", ilp(R.myers_body(nw, 1, split=MYERS_SPLIT, park=MYERS_PARK, balanced=MYERS_BALANCED)), 2 * nw, nw))
     parts.append("\n// Short subjects: the row is so short that the scalar dispatch bounds the loop, so a stream token\n"
                  "// carries two rows (bgsa_common.h: pair_stream_window).\n"
                  "// G = 2: two subject groups per wave — twice the vector work behind every dispatch, and these bodies are so\n"
@@ -1509,7 +1518,7 @@ def main() -> int:
                  "                                                      const uint32_t (&B)[3 * NW],\n"
                  "                                                      const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_PLANES_NW:
-        parts.append(gen_function("myers_planes_rows_asm", f"{nw}", ilp(R.myers_planes_body(nw, MYERS_PLANES_SPLIT if nw >= 30 else 0)),
+        parts.append(gen_function("myers_planes_rows_asm", f"{nw}", ilp_planes(R.myers_planes_body(nw, MYERS_PLANES_SPLIT if nw >= 30 else 0, balanced=MYERS_BALANCED)),
                                   2 * nw, 0, n_planes=3 * nw))
     parts.append("\n// Semi-global on the code planes (subjects of 769..1024 bp): rows_ir.py: myers_semi_planes_body — the unused low\n"
                  "// columns carry code 7, which matches every class; 9 VALU per word + 3 per row.\n"

@@ -18,9 +18,10 @@
 //     D[m][n] = m + popcount(VP & mask) - popcount(VN & mask), two v_bcnt per word.
 //
 // Three kernels, chosen by launch_myers():
-//   myers_global_asm_kernel<NW,1>   1..768 bp    generated asm row loop, Peq planes resident, 8 VALU per (row, word)
-//   myers_global_planes_kernel<NW>  769..1024 bp generated asm row loop on 3-bit character-code
-//                                                planes, 9 VALU per (row, word)
+//   myers_global_asm_kernel<NW,1>   1..1024 bp   generated asm row loop, Peq planes resident, 8 VALU per (row, word); 30 and 32 words
+//                                                (897..1024 bp) with the two carry chains in turns over blocks of 8 words
+//   myers_global_planes_kernel<NW>  (A/B)        generated asm row loop on 3-bit character-code planes, 9 VALU per (row, word):
+//                                                897..1024 bp until round 5, now under BGSA_MYERS_PEQ_MAX_WORDS
 //   myers_global_kernel<NW,1>       compiler-scheduled C++ of the same recurrence: the A/B
 //                                   reference for the asm (BGSA_MYERS_IMPL=c), 124 vs 216 TCUPS
 //   myers_blocked_kernel<NW>        > 1024 bp    column blocks of the planes body, carries between
@@ -162,7 +163,11 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 }
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
-constexpr int kPeqMaxWords = 28;  // default of myers_peq_max_words(): measured faster than the code planes up to here
+// default of myers_peq_max_words(): the widest subject with its five Peq planes resident.  28 until round 5; 30 and 32 words since then
+// — their rows run the two carry chains in turns over blocks of eight words (rows_ir.myers_body(split = 8)), which holds 16 temporaries
+// where the row-long phases hold 64: 253 VGPRs, eight instructions per word against nine on the code planes (config 5: 4,214 -> 4,036 ms,
+// profiles/r05_balance_ab.txt).  BGSA_MYERS_PEQ_MAX_WORDS=28 puts 29 .. 32 words back on the code planes (A/B).
+constexpr int kPeqMaxWords = 32;
 constexpr int kSemiPeqMaxWords = 25;  // widest semi-global kernel with resident Peq planes (myers_semi_rows_asm)
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"

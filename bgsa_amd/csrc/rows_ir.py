@@ -439,7 +439,7 @@ def _dependencies(ops):
     return deps
 
 
-def schedule_ilp(body: "Body", gap: int = 1, window: int = 24) -> "Body":
+def schedule_ilp(body: "Body", gap: int = 1, window: int = 24, vcc_dist: int = 3) -> "Body":
     """List-schedule a straight-line body so that no instruction issues right behind the one whose result it reads.
 
     Why (round 5): the Myers rows are, as written, ONE dependent chain — a = VP & E feeds the add, the add feeds HN, HN feeds M2,
@@ -454,7 +454,7 @@ def schedule_ilp(body: "Body", gap: int = 1, window: int = 24) -> "Body":
     ops = body.ops
     n = len(ops)
     deps = _dependencies(ops)
-    need = {"raw": gap + 1, "vcc": 3, "order": 1}
+    need = {"raw": gap + 1, "vcc": max(3, vcc_dist), "order": 1}   # vcc_dist: instructions from one carry link to the next (>= 3: two wait states)
     succs = [[] for _ in range(n)]
     for i in range(n):
         for p_, _ in deps[i]:
@@ -518,7 +518,7 @@ def dependent_pairs(body: "Body") -> int:
 MYERS_EIGHT = __import__('os').environ.get('BGSA_GEN_MYERS_EIGHT', '1') != '0'   # '0': the 10-instruction rows of rounds 1-3 (A/B builds)
 
 
-def myers_body(nw: int, groups: int = 1, split: int = 0, park: str = "sgpr") -> Body:
+def myers_body(nw: int, groups: int = 1, split: int = 0, park: str = "sgpr", balanced: bool = False) -> Body:
     """State layout: S[(g*nw + w)*2 + 0] = VP word w of group g, +1 = VN.  E[g*nw + w] = match mask.
 
     Per word EIGHT instructions and two carry chains (round 4; ten and three until then: myers_body10).  In the terms of the
@@ -538,7 +538,9 @@ def myers_body(nw: int, groups: int = 1, split: int = 0, park: str = "sgpr") -> 
     kernel's own registers <= 256) where they ran on the code planes, nine instructions per word, before.
     park = "vgpr": the pausing chain waits in a vector register (SAVEV / LOADV: one fast-class VALU instruction each, two more
     temporaries) instead of a scalar pair — a scalar move of VCC waits for the vector pipe to drain, and at two waves per
-    SIMD nobody fills the gap."""
+    SIMD nobody fills the gap.
+    balanced: HP of word w + 1 is formed in phase B, between the shift of word w and its new deltas, instead of at the end of
+    phase A — four instructions from carry link to carry link in BOTH phases where the order above has five and three."""
     if not MYERS_EIGHT:
         return myers_body10(nw, groups)
     b = Body()
@@ -559,19 +561,24 @@ def myers_body(nw: int, groups: int = 1, split: int = 0, park: str = "sgpr") -> 
                 (b.ADD_CO if w == 0 else b.ADDC)(M(w), VP(w), A(w))
                 if w == hi - 1 and not last and not vg:
                     save(0)
+                if w == hi - 1 and not vg and balanced and hi - lo > 1:
+                    b.SETC1() if first else load(1)      # balanced: only two instructions of this phase are left behind it
                 b.BITOP3(A(w), M(w), VP(w), A(w), lambda s_, vp, a: s_ ^ vp ^ a)
-                if w == hi - 1 and not vg:
+                if w == hi - 1 and not vg and not (balanced and hi - lo > 1):
                     # the other chain's carry, two instructions ahead of its reader; block 0: the row edge D[i][0] - D[i-1][0] = +1
                     # enters HP at bit 0 of word 0
                     b.SETC1() if first else load(1)
                 b.BITOP3(M(w), E(w), VN(w), A(w), lambda e, vn, hn: e | vn | hn)
                 if w == hi - 1 and not last and vg:
                     save(0)          # a VALU read of VCC: two instructions behind the link that wrote it
-                b.BITOP3(VP(w), M(w), VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+                if not balanced or w == lo:
+                    b.BITOP3(VP(w), M(w), VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
                 if w == hi - 1 and vg:
                     b.SETC1() if first else load(1)     # (as written its reader follows at once: schedule_ilp, or the emitter's s_nop, spaces them)
             for w in range(lo, hi):  # phase B: HP << 1 across words, then the new deltas
                 b.ADDC(VP(w), VP(w), VP(w))
+                if balanced and w + 1 < hi:
+                    b.BITOP3(VP(w + 1), M(w + 1), VN(w + 1), VP(w + 1), lambda m, vn, vp: (m & vn) | ~(m | vp))
                 if w == hi - 1 and not last and not vg:
                     save(1)
                 b.AND(VN(w), M(w), VP(w))
@@ -751,7 +758,7 @@ def myers_semi_simulate(subjects: np.ndarray, query: np.ndarray, nw: int) -> np.
     return (-st[2 * nw + 1].astype(np.int64)).astype(np.int16)
 
 
-def myers_planes_body(nw: int, split: int = 0) -> Body:
+def myers_planes_body(nw: int, split: int = 0, balanced: bool = False) -> Body:
     """Myers for long subjects (769..1024 bp): the five Peq planes of a subject (5*nw registers)
     are replaced by its 3-bit character code planes B[w*3+i] (3*nw registers) and the match mask
     of the row's class is rebuilt per word with one v_bitop3 (MATCH3) — 11 instructions per word,
@@ -777,9 +784,12 @@ def myers_planes_body(nw: int, split: int = 0) -> Body:
                 if w == hi - 1 and split:
                     b.SETC1() if first else b.LOADCC(1)
                 b.BITOP3(f"m{w}", f"e{w}", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
-                b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+                if not balanced or w == lo:
+                    b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
             for w in range(lo, hi):
                 b.ADDC(VP(w), VP(w), VP(w))
+                if balanced and w + 1 < hi:   # HP of the next word between this word's shift and its new deltas (myers_body: balanced)
+                    b.BITOP3(VP(w + 1), f"m{w + 1}", VN(w + 1), VP(w + 1), lambda m, vn, vp: (m & vn) | ~(m | vp))
                 if w == hi - 1 and not last:
                     b.SAVECC(1)
                 b.AND(VN(w), f"m{w}", VP(w))

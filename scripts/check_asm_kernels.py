@@ -6,7 +6,7 @@ clobbers, and take the query-stream address in an SGPR pair.  This script compil
 units to gfx950 assembly and checks what the compiler did around the asm blocks:
 
   1. the operands the compiler hands into a block, and takes out of it, never sit in a register the loop
-     hard-codes (s60..s71, the column-block loops' s80/s81, the banded loop's s72..s95) — the clobber list
+     hard-codes (s60..s71, s72..s75 of the rows that park a carry chain, the column-block loops' s80/s81, the banded loop's s72..s95) — the clobber list
      is the contract, this checks the compiler kept it (the compiler may and does reuse those registers for
      its own temporaries BETWEEN blocks);
   2. no s_bfe_i64 in an asm kernel — the signature of round 1's fault: the stream address built as
@@ -30,6 +30,8 @@ CSRC = ROOT / "bgsa_amd" / "csrc"
 def clobbered(func: str) -> set:
     """The hard-coded SGPRs of the loop a kernel carries (gen_rows_asm.py: CLOBBERS and the per-loop extras)."""
     regs = set(range(60, 72))
+    if re.search(r"myers_global_asm_kernelILi3[02]E", func):     # 30 / 32 words: the parked carry chains (gen_rows_asm.py: S_PARK)
+        regs |= {72, 73, 74, 75}
     if "blocked_kernel" in func:
         regs |= {80, 81}
     if "banded_asm_kernel" in func:
