@@ -371,44 +371,49 @@ def total_gcups_leg(algo, k, scores, q_host, s_rows_dev, ns, ns_pad, length, dev
 
 
 class PowerSampler:
-    """rocm-smi's power and shader clock sampled on the host while the timed region runs (a thread that starts `rocm-smi
-    --showpower --showclocks --json` about once a second: host work only, nothing is launched on the GPU).  The headline kernel is
-    power-bound (LABNOTES §9.5): the clock the chip holds under it — 2.2-2.3 of the nominal 2.4 GHz — is the box-to-box spread of
-    the headline number, and this puts the watts beside it.  Best effort: any failure leaves `None`."""
+    """The GPU's power and shader clock as the driver's hwmon files report them (/sys/class/drm/card*/device/hwmon/hwmon*/
+    power1_average | power1_input in microwatts, freq1_input in Hz), read on the host about five times a second while the timed
+    region runs: plain file reads from a thread — nothing is launched on the GPU and NO program is started (rocm-smi is a script
+    whose interpreter would have to be exec'ed from a process that has initialised the GPU, which the GPU boxes refuse, rightly).
+    The headline kernel is power-bound (LABNOTES §9.5): the clock the chip holds under it is the box-to-box spread of the headline
+    number, and this puts the watts beside it.  Best effort: where the files are absent or unreadable the line carries `null`."""
 
-    def __init__(self, period_s: float = 1.0):
+    def __init__(self, period_s: float = 0.2):
+        import glob
         self.period, self.samples, self._stop, self._thread = period_s, [], threading.Event(), None
+        self.dirs = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
 
-    def _once(self):
-        import re
-        import subprocess
+    @staticmethod
+    def _read(path):
         try:
-            p = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
-            cards = json.loads(p.stdout[p.stdout.index("{"):])
+            with open(path) as f:
+                return float(f.read().strip())
         except Exception:
             return None
-        out = {}
-        for card, kv in cards.items():
-            if not isinstance(kv, dict):
-                continue
-            for key, val in kv.items():
-                m = re.search(r"-?\d+(\.\d+)?", str(val))
-                if not m:
-                    continue
-                if re.search(r"power", key, re.I) and re.search(r"\(W\)|watt", key, re.I):
-                    out.setdefault("watts", []).append(float(m.group()))
-                elif re.search(r"sclk", key, re.I):
-                    out.setdefault("sclk_mhz", []).append(float(m.group()))
-        return out or None
+
+    def _once(self):
+        watts, mhz = [], []
+        for d in self.dirs:
+            w = self._read(d + "/power1_average")
+            if w is None:
+                w = self._read(d + "/power1_input")
+            if w is not None:
+                watts.append(w / 1e6)
+            f = self._read(d + "/freq1_input")
+            if f is not None:
+                mhz.append(f / 1e6)
+        return {"watts": watts, "sclk_mhz": mhz} if (watts or mhz) else None
 
     def start(self):
+        if not self.dirs:
+            return self
+
         def loop():
             while not self._stop.is_set():
-                t0 = time.time()
                 one = self._once()
                 if one:
                     self.samples.append(one)
-                self._stop.wait(max(0.05, self.period - (time.time() - t0)))
+                self._stop.wait(self.period)
         self._thread = threading.Thread(target=loop, daemon=True)
         self._thread.start()
         return self
@@ -416,16 +421,17 @@ class PowerSampler:
     def stop(self):
         self._stop.set()
         if self._thread is not None:
-            self._thread.join(timeout=6)
+            self._thread.join(timeout=2)
         if not self.samples:
             return None
-        # one GPU box: the busiest card of every sample is the one under the kernel (others, if rocm-smi lists any, idle)
+        # the busiest card of every sample is the one under the kernel (a box may list idle neighbours)
         watts = [max(x["watts"]) for x in self.samples if x.get("watts")]
         sclk = [max(x["sclk_mhz"]) for x in self.samples if x.get("sclk_mhz")]
-        return {"samples": len(self.samples), "watts_mean": round(float(np.mean(watts)), 1) if watts else None,
+        return {"samples": len(self.samples), "cards_seen": len(self.dirs),
+                "watts_mean": round(float(np.mean(watts)), 1) if watts else None,
                 "watts_max": round(max(watts), 1) if watts else None,
                 "sclk_mhz_mean": round(float(np.mean(sclk)), 1) if sclk else None,
-                "source": "rocm-smi --showpower --showclocks --json, about once a second on the host while the timed region ran"}
+                "source": "hwmon power1_average / freq1_input of /sys/class/drm/card*, read on the host during the timed region"}
 
 
 class RunWatchdog:
@@ -975,7 +981,7 @@ def main() -> int:
                 # issued x 64 lanes / kernel time / peak, at the nominal and at the sustained clock; instructions per (query row, wave)
                 **flat_issued(issued),
                 "sustained_mhz": clock["sustained_mhz"] if clock else None,       # the clock the chip held under the timed kernels (probe waves)
-                "watts_mean": power["watts_mean"] if power else None,            # and the power it drew (rocm-smi, host-side sampling)
+                "watts_mean": power["watts_mean"] if power else None,            # and the power it drew (hwmon files, host-side sampling)
                 "issued": issued,
                 "traffic": traffic,
                 "traffic_source": pmc_src if (traffic or pmc is None) else None,
@@ -985,7 +991,7 @@ def main() -> int:
                 "kernel_ms": round(kernel_s * 1e3, 3),
                 "kernel_gcups": round(kernel_gcups, 1),
                 "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; kernel time from HIP events on the launch stream; "
-                        "traffic_ratio > 1: the kernels tile 32 queries per Peq load where SURVEY's byte model assumes 100",
+                        "traffic_ratio = counter bytes / SURVEY's algorithmic bytes (its model: one Peq block per 100 queries; the counter launches tile up to 128)",
                 "hbm": {"bound": "hbm", "achieved": round(algorithmic_bytes / kernel_s / 1e9, 2), "peak": HBM_PEAK / 1e9,
                         "unit": "GB/s", "frac": round(algorithmic_bytes / kernel_s / HBM_PEAK, 6),
                         "bytes_per_pair": round(bpp, 3),

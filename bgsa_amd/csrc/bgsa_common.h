@@ -408,12 +408,25 @@ struct TaskPlan {
     int q_tile;
     bool dynamic;
 };
-inline TaskPlan plan_tasks(int nq, long long wave_tasks_per_tile, long long row_words, int q_max, bool counter_kernel)
+// Most queries per task of a counter launch.  A task loads its group's Peq block once and walks its queries, so the launch's HBM traffic is
+// 2 B per score + block bytes / tile per pair: tiles of 32 (Myers) and 16 (BitPAl) — rounds 1-4 — read 1.7 x and 2.8 x SURVEY's
+// algorithmic bytes (its model assumes the reference's 100-query blocks), 128 read 0.93 x.  At < 1 % of HBM peak neither costs time; the
+// tile is still halved towards the task target for launches that need the tasks.  BGSA_QUERY_TILE_MAX (power of two, 8 .. 256) is the knob.
+inline int query_tile_max()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_QUERY_TILE_MAX");
+        const int t = e ? atoi(e) : 128;
+        return (t >= 8 && t <= 256 && (t & (t - 1)) == 0) ? t : 128;
+    }();
+    return v;
+}
+inline TaskPlan plan_tasks(int nq, long long wave_tasks_per_tile, long long row_words, int q_max, bool counter_kernel, int q_max_counter = 0)
 {
     static const long long target = [] { const char *e = getenv("BGSA_DYNAMIC_TASK_TARGET"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 262144ll; }();
     static const long long words = [] { const char *e = getenv("BGSA_DYNAMIC_TASK_WORDS"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 3000ll; }();
     if (counter_kernel && dynamic_tasks()) {
-        const int q = pick_query_tile(nq, wave_tasks_per_tile, row_words, q_max, target, words);
+        const int q = pick_query_tile(nq, wave_tasks_per_tile, row_words, q_max_counter > 0 ? q_max_counter : q_max, target, words);
         if (dynamic_tasks_fit(((nq + q - 1) / q) * wave_tasks_per_tile)) return {q, true};
     }
     return {pick_query_tile(nq, wave_tasks_per_tile, row_words, q_max), false};

@@ -381,7 +381,8 @@ int launch_nw(const char *d_content, const uint32_t *d_peq, int16_t *d_results, 
         [] { int a = 0, b = 0;
              return hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bitpal_asm_kernel<NW, true, false>, 256, 0) == hipSuccess &&
                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bitpal_asm_kernel<NW, true, true>, 256, 0) == hipSuccess && b >= a && a > 0; }()};
-    const TaskPlan plan = plan_tasks(nq, n_groups, static_cast<long long>(ref_len) * NW * 2, 16, NW <= 8 && counter_costs_no_wave[semi ? 1 : 0]);
+    const TaskPlan plan = plan_tasks(nq, n_groups, static_cast<long long>(ref_len) * NW * 2, 16, NW <= 8 && counter_costs_no_wave[semi ? 1 : 0],
+                                     query_tile_max());
     const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock - 1) / kWavesPerBlock),

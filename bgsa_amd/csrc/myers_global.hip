@@ -647,6 +647,20 @@ static unsigned myers_lds_pad()
     return v;
 }
 
+// Most queries per task of the 30- and 32-word kernels.  A task loads the group's 160 Peq words once and walks its queries, so the
+// tile is what the launch's HBM traffic hangs on: 8 (the code-plane kernels' choice: their tasks are long) re-read the 660 B per
+// subject 125 times per 1,000 queries — 83 GB per config-5 pass, 9.7 x SURVEY's algorithmic bytes —, 32 a quarter of that.  Neither costs
+// time at < 1 % of HBM peak; BGSA_MYERS_LONG_TILE (8 | 16 | 32) is the measurement knob.
+static int long_query_tile()
+{
+    static const int v = [] {
+        const char *e = getenv("BGSA_MYERS_LONG_TILE");
+        const int t = e ? atoi(e) : 32;
+        return (t == 8 || t == 16 || t == 32) ? t : 32;
+    }();
+    return v;
+}
+
 template <int NW, int G>
 int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results, int ref_len,
                int read_len, int64_t read_count, int ref_start, int ref_end, int word_num,
@@ -655,9 +669,10 @@ int launch_asm(const char *d_content, const uint32_t *d_peq, int16_t *d_results,
     const int nq = ref_end - ref_start;
     const int64_t n_groups = read_count / kLanes;
     // the widths with registers to spare have a counter instantiation, and so have the split-chain widths (30, 32 words: two
-    // waves per SIMD with or without the task loop's registers; their tasks are long, so at most 8 queries each, as on the code planes)
+    // waves per SIMD with or without the task loop's registers)
     constexpr bool kCounter = NW <= 8 || NW >= 30;
-    const TaskPlan plan = plan_tasks(nq, (n_groups + G - 1) / G, static_cast<long long>(ref_len) * NW * G, NW >= 30 ? 8 : 32, kCounter);
+    const TaskPlan plan = plan_tasks(nq, (n_groups + G - 1) / G, static_cast<long long>(ref_len) * NW * G, NW >= 30 ? 8 : 32, kCounter,
+                                     NW >= 30 ? long_query_tile() : query_tile_max());
     const int q_tile = plan.q_tile;
     note_query_tile(q_tile);
     dim3 grid(static_cast<unsigned>((n_groups + kWavesPerBlock * G - 1) / (kWavesPerBlock * G)),
