@@ -44,6 +44,28 @@ def test_query_stream_window_boundaries(oracle, qlen):
     assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_BITPAL), oracle.bitpal(q, s))
 
 
+@pytest.mark.parametrize("qlen,slen", [(120, 897), (333, 929), (1000, 960), (64, 961), (990, 992), (997, 1000), (1100, 1023), (1021, 1024)])
+def test_myers_897_to_1024_bp_on_resident_peq_planes(oracle, qlen, slen):
+    """30 and 32 words (round 5): five Peq planes resident, the two carry chains in turns over blocks of eight words
+    (rows_ir.myers_body(split = 8)).  Reads with N columns, homopolymers (carries through every word and across every block
+    boundary of a chain's turn) and near-copies, against the oracle."""
+    L = B.lib()
+    L.bgsa_hip_select_alignment(0)
+    assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, (slen + 31) // 32).startswith(b"myers_global_asm_kernel<%d, 1>" % (30 if slen <= 960 else 32))
+    q = oracle.gen_reads(8100 + qlen, 6, qlen)
+    s = oracle.gen_reads(8200 + slen, 140, slen)
+    m = min(qlen, slen)
+    s[:24, :m] = oracle.mutate(q[np.arange(24) % 6][:, :m], np.arange(24) % 9, 8300)
+    s[30] = ord("A")
+    s[31] = ord("N")
+    s[32, ::2] = ord("C")
+    s[33, 255:290] = ord("N")           # across the boundary of the first and second turn (words 7 | 8)
+    q[4] = ord("A")
+    q[5, : qlen // 2] = ord("N")
+    assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), oracle.myers64(q, s))
+    assert L.bgsa_hip_stream_faults(1) == 0
+
+
 def test_myers_query_tiles_and_offsets(oracle):
     # ref_start/ref_end windows and many queries (several q-tiles), odd row alignment (stride 151)
     q = oracle.gen_reads(31, 203, 150)
@@ -1273,7 +1295,7 @@ import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 import bgsa_amd as B, oracle as O
 q = O.gen_reads(901, 3, 310)
-for slen in (150, 310, 700, 1100, 2300):
+for slen in (150, 310, 700, 930, 1000, 1100, 2300):   # 930 / 1000 bp: 30 / 32 words, the carry chains in turns (code planes under BGSA_MYERS_PEQ_MAX_WORDS=28)
     s = O.gen_reads(902 + slen, 130, slen)
     m = min(310, slen)
     s[:10, :m] = O.mutate(q[np.arange(10) % 3][:, :m], np.arange(10), 903)
@@ -1333,6 +1355,9 @@ print("knobs ok")
                                  {"BGSA_MYERS_MAX_PLAIN_WORDS": "8"},
                                  {"BGSA_MYERS_MAX_PLAIN_WORDS": "8", "BGSA_MYERS_BLOCK_FORM": "planes"},
                                  {"BGSA_MYERS_PEQ_MAX_WORDS": "8"},
+                                 {"BGSA_MYERS_PEQ_MAX_WORDS": "28"},                          # 29 .. 32 words on the code planes (the default until round 5)
+                                 {"BGSA_QUERY_TILE_MAX": "8", "BGSA_DYNAMIC_MIN_TASKS": "1"},    # counter launches with small query tiles
+                                 {"BGSA_QUERY_TILE_MAX": "256", "BGSA_MYERS_LONG_TILE": "8", "BGSA_DYNAMIC_MIN_TASKS": "1"},
                                  {"BGSA_BLOCKED_WORKGROUPS": "96"}])
 def test_measurement_knobs_do_not_change_results(env):
     import os
