@@ -392,17 +392,14 @@ class PowerSampler:
             return None
 
     def _once(self):
-        watts, mhz = [], []
+        cards = []
         for d in self.dirs:
             w = self._read(d + "/power1_average")
             if w is None:
                 w = self._read(d + "/power1_input")
-            if w is not None:
-                watts.append(w / 1e6)
             f = self._read(d + "/freq1_input")
-            if f is not None:
-                mhz.append(f / 1e6)
-        return {"watts": watts, "sclk_mhz": mhz} if (watts or mhz) else None
+            cards.append((w / 1e6 if w is not None else None, f / 1e6 if f is not None else None))
+        return cards if any(w is not None for w, _ in cards) else None
 
     def start(self):
         if not self.dirs:
@@ -424,14 +421,18 @@ class PowerSampler:
             self._thread.join(timeout=2)
         if not self.samples:
             return None
-        # the busiest card of every sample is the one under the kernel (a box may list idle neighbours)
-        watts = [max(x["watts"]) for x in self.samples if x.get("watts")]
-        sclk = [max(x["sclk_mhz"]) for x in self.samples if x.get("sclk_mhz")]
-        return {"samples": len(self.samples), "cards_seen": len(self.dirs),
+        # a box may list idle neighbours (eight cards on the host, one of them ours): the card under the kernel is the one that
+        # drew the most power over the region; its clock file reads the shader clock of that card
+        n = len(self.samples[0])
+        mean_w = [float(np.mean([s_[i][0] for s_ in self.samples if s_[i][0] is not None] or [0.0])) for i in range(n)]
+        busy = int(np.argmax(mean_w))
+        watts = [s_[busy][0] for s_ in self.samples if s_[busy][0] is not None]
+        sclk = [s_[busy][1] for s_ in self.samples if s_[busy][1] is not None]
+        return {"samples": len(self.samples), "cards_seen": n, "card": self.dirs[busy].split("/")[4],
                 "watts_mean": round(float(np.mean(watts)), 1) if watts else None,
                 "watts_max": round(max(watts), 1) if watts else None,
                 "sclk_mhz_mean": round(float(np.mean(sclk)), 1) if sclk else None,
-                "source": "hwmon power1_average / freq1_input of /sys/class/drm/card*, read on the host during the timed region"}
+                "source": "hwmon power1_average / freq1_input of the busiest /sys/class/drm/card*, read on the host during the timed region"}
 
 
 class RunWatchdog:
