@@ -795,6 +795,14 @@ def main() -> int:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             print(f"[bench] rank {rank}: gather set-up failed ({setup_error or 'on another rank'})", file=sys.stderr)
+            if rank == 0:       # the contract is ONE parseable line whatever happens: the kernels-only figure and what went wrong
+                with wd.lock:
+                    line = wd.stub()
+                    line.update(kernel_only=kernel_only, gather={"error": f"set-up failed: {setup_error or 'on another rank'}"},
+                                gather_ok=False, rccl_ok=False)
+                    print(json.dumps(line), flush=True)
+                    wd.printed = True
+            wd.cancel()
             return 4
 
         def gathered_step():

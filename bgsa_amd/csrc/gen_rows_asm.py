@@ -40,7 +40,10 @@ MYERS_PARKED_NW = [18, 26, 28]
 # MYERS_SPLIT words (rows_ir.myers_body(split=K)), so a row holds 2K temporaries instead of 2*nw: 7*nw + 2K + the kernel's own
 # registers <= 256.  Until then these widths ran on the code planes (nine instructions per word).
 MYERS_SPLIT_NW = [30, 32]
-MYERS_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_SPLIT", "8"))
+# Block size: K = 4 / 6 / 7 / 8 / 9 / 10 / 11 / 12 measured (config 5, ms per pass; profiles/r05_split_ab.txt, r05_split_k_ab.txt, r05_split_k9.txt):
+# static grids 4,855 / 4,287 / 4,174 / 4,174 / 4,132 / 4,114 / (4,250 against 4,107 on another box) / 4,379; the counter instantiation,
+# worth 1 - 3.5 %, fits 256 VGPRs up to K = 9 (255): K = 8 4,036 - 4,040, K = 9 3,980 - 3,985 (930 bp: 1,846 -> 1,805).
+MYERS_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_SPLIT", "9"))
 MYERS_PARK = os.environ.get("BGSA_GEN_MYERS_PARK", "sgpr")     # where the pausing chain waits: a scalar pair, or "vgpr" (two more VALU per switch)
 # "gap,window[,instructions from carry link to carry link]" of rows_ir.schedule_ilp for the Myers GLOBAL bodies with resident Peq planes
 # ("0" = the bodies as written: every instruction right behind the one it reads from).  Default 2,24 since round 5, same-box A/Bs in

@@ -19,7 +19,7 @@
 //
 // Three kernels, chosen by launch_myers():
 //   myers_global_asm_kernel<NW,1>   1..1024 bp   generated asm row loop, Peq planes resident, 8 VALU per (row, word); 30 and 32 words
-//                                                (897..1024 bp) with the two carry chains in turns over blocks of 8 words
+//                                                (897..1024 bp) with the two carry chains in turns over blocks of 9 words
 //   myers_global_planes_kernel<NW>  (A/B)        generated asm row loop on 3-bit character-code planes, 9 VALU per (row, word):
 //                                                897..1024 bp until round 5, now under BGSA_MYERS_PEQ_MAX_WORDS
 //   myers_global_kernel<NW,1>       compiler-scheduled C++ of the same recurrence: the A/B
@@ -164,9 +164,9 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 
 // ---- generated row loop (gen_rows_asm.py) ----------------------------------------------------------
 // default of myers_peq_max_words(): the widest subject with its five Peq planes resident.  28 until round 5; 30 and 32 words since then
-// — their rows run the two carry chains in turns over blocks of eight words (rows_ir.myers_body(split = 8)), which holds 16 temporaries
-// where the row-long phases hold 64: 253 VGPRs, eight instructions per word against nine on the code planes (config 5: 4,214 -> 4,036 ms,
-// profiles/r05_balance_ab.txt).  BGSA_MYERS_PEQ_MAX_WORDS=28 puts 29 .. 32 words back on the code planes (A/B).
+// — their rows run the two carry chains in turns over blocks of nine words (rows_ir.myers_body(split = 9)), which holds 18 temporaries
+// where the row-long phases hold 64: 255 VGPRs, eight instructions per word against nine on the code planes (config 5: 4,214 -> 3,980 ms,
+// profiles/r05_balance_ab.txt, r05_split_k9.txt).  BGSA_MYERS_PEQ_MAX_WORDS=28 puts 29 .. 32 words back on the code planes (A/B).
 constexpr int kPeqMaxWords = 32;
 constexpr int kSemiPeqMaxWords = 25;  // widest semi-global kernel with resident Peq planes (myers_semi_rows_asm)
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)

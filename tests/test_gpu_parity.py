@@ -46,8 +46,8 @@ def test_query_stream_window_boundaries(oracle, qlen):
 
 @pytest.mark.parametrize("qlen,slen", [(120, 897), (333, 929), (1000, 960), (64, 961), (990, 992), (997, 1000), (1100, 1023), (1021, 1024)])
 def test_myers_897_to_1024_bp_on_resident_peq_planes(oracle, qlen, slen):
-    """30 and 32 words (round 5): five Peq planes resident, the two carry chains in turns over blocks of eight words
-    (rows_ir.myers_body(split = 8)).  Reads with N columns, homopolymers (carries through every word and across every block
+    """30 and 32 words (round 5): five Peq planes resident, the two carry chains in turns over blocks of nine words
+    (rows_ir.myers_body(split = 9)).  Reads with N columns, homopolymers (carries through every word and across every block
     boundary of a chain's turn) and near-copies, against the oracle."""
     L = B.lib()
     L.bgsa_hip_select_alignment(0)
@@ -59,7 +59,7 @@ def test_myers_897_to_1024_bp_on_resident_peq_planes(oracle, qlen, slen):
     s[30] = ord("A")
     s[31] = ord("N")
     s[32, ::2] = ord("C")
-    s[33, 255:290] = ord("N")           # across the boundary of the first and second turn (words 7 | 8)
+    s[33, 280:300] = ord("N")           # across the boundary of the first and second turn (words 8 | 9)
     q[4] = ord("A")
     q[5, : qlen // 2] = ord("N")
     assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS), oracle.myers64(q, s))

@@ -535,8 +535,8 @@ def test_myers_eight_instruction_row_equals_the_ten_instruction_row(nw, groups):
 
 
 # ---- round 5: the two carry chains in turns over blocks of K words (SAVECC / LOADCC), and the dependency-aware order ----
-@pytest.mark.parametrize("qlen,slen,nw,split", [(120, 1000, 32, 8), (60, 930, 30, 8), (200, 1024, 32, 4), (150, 150, 5, 2), (90, 257, 9, 3),
-                                                (40, 1000, 32, 12)])
+@pytest.mark.parametrize("qlen,slen,nw,split", [(120, 1000, 32, 9), (60, 930, 30, 9), (200, 1024, 32, 8), (150, 1000, 32, 4), (150, 150, 5, 2),
+                                                (90, 257, 9, 3), (40, 1000, 32, 12)])
 def test_myers_split_body_matches_oracle(oracle, qlen, slen, nw, split):
     """myers_body(split=K): phase A and phase B of K words at a time, the pausing chain parked in a scalar pair — the form
     that keeps five Peq planes resident at 30 / 32 words.  Against the oracle, with reads that drive the carries through
@@ -561,7 +561,7 @@ def test_myers_split_body_matches_oracle(oracle, qlen, slen, nw, split):
 
 
 @pytest.mark.parametrize("make,nw,planes", [(lambda: R.myers_body(5), 5, False), (lambda: R.myers_body(3, groups=2), 6, False),
-                                             (lambda: R.myers_body(32, 1, split=8), 32, False),
+                                             (lambda: R.myers_body(32, 1, split=9), 32, False),
                                              (lambda: R.myers_planes_body(32), 32, True), (lambda: R.myers_planes_body(30, split=8), 30, True)])
 @pytest.mark.parametrize("gap,window", [(1, 12), (2, 24)])
 def test_schedule_ilp_keeps_the_function_and_separates_dependent_instructions(make, nw, planes, gap, window):
