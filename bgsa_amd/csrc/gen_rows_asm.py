@@ -44,6 +44,7 @@ MYERS_SPLIT_NW = [30, 32]
 # static grids 4,855 / 4,287 / 4,174 / 4,174 / 4,132 / 4,114 / (4,250 against 4,107 on another box) / 4,379; the counter instantiation,
 # worth 1 - 3.5 %, fits 256 VGPRs up to K = 9 (255): K = 8 4,036 - 4,040, K = 9 3,980 - 3,985 (930 bp: 1,846 -> 1,805).
 MYERS_SPLIT = int(os.environ.get("BGSA_GEN_MYERS_SPLIT", "9"))
+MYERS_SEMI_SPLIT_NW = [26, 28, 30, 32]   # semi-global beyond 25 words with resident Peq planes (round 5; on the code planes before: MYERS_SEMI_PLANES_NW)
 MYERS_PARK = os.environ.get("BGSA_GEN_MYERS_PARK", "sgpr")     # where the pausing chain waits: a scalar pair, or "vgpr" (two more VALU per switch)
 # "gap,window[,instructions from carry link to carry link]" of rows_ir.schedule_ilp for the Myers GLOBAL bodies with resident Peq planes
 # ("0" = the bodies as written: every instruction right behind the one it reads from).  Default 2,24 since round 5, same-box A/Bs in
@@ -1515,6 +1516,8 @@ def main() -> int:
                  "                                                   const unsigned long long stream, const int n_windows);\n")
     for nw in MYERS_NW:
         parts.append(gen_function("myers_semi_rows_asm", f"{nw}", R.myers_semi_body(nw), 2 * nw + 2, nw))
+    for nw in MYERS_SEMI_SPLIT_NW:   # 801..1024 bp: the chains in turns (as the global kernels of 30 / 32 words), scheduled
+        parts.append(gen_function("myers_semi_rows_asm", f"{nw}", ilp(R.myers_semi_body(nw, split=MYERS_SPLIT)), 2 * nw + 2, nw))
     parts.append("\n// Long subjects (NW 26..32; the widths below 26 serve the column-block kernel and A/B runs): 3-bit character-code planes B[w*3+i] instead of five Peq planes.\n"
                  "template <int NW>\n"
                  "__device__ __forceinline__ int myers_planes_rows_asm(uint32_t (&state)[2 * NW],\n"

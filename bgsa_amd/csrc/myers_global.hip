@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void myers_global_kernel(
 // where the row-long phases hold 64: 255 VGPRs, eight instructions per word against nine on the code planes (config 5: 4,214 -> 3,980 ms,
 // profiles/r05_balance_ab.txt, r05_split_k9.txt).  BGSA_MYERS_PEQ_MAX_WORDS=28 puts 29 .. 32 words back on the code planes (A/B).
 constexpr int kPeqMaxWords = 32;
-constexpr int kSemiPeqMaxWords = 25;  // widest semi-global kernel with resident Peq planes (myers_semi_rows_asm)
+constexpr int kSemiPeqMaxWords = 32;  // widest semi-global kernel with resident Peq planes (myers_semi_rows_asm; 26..32 words: chains in turns, round 5)
 constexpr int kPairMaxWords = 2;  // widths instantiated as myers_pair_rows_asm (gen_rows_asm.py: MYERS_PAIR_NW)
 #include "myers_rows_gen.inc"
 
@@ -982,7 +982,7 @@ int launch_myers(const char *d_content, const uint32_t *d_peq, int16_t *d_result
                 BGSA_SEMI_CASE(1) BGSA_SEMI_CASE(2) BGSA_SEMI_CASE(3) BGSA_SEMI_CASE(4) BGSA_SEMI_CASE(5)
                 BGSA_SEMI_CASE(6) BGSA_SEMI_CASE(7) BGSA_SEMI_CASE(8) BGSA_SEMI_CASE(10) BGSA_SEMI_CASE(12)
                 BGSA_SEMI_CASE(14) BGSA_SEMI_CASE(16) BGSA_SEMI_CASE(18) BGSA_SEMI_CASE(20) BGSA_SEMI_CASE(22)
-                BGSA_SEMI_CASE(24) BGSA_SEMI_CASE(25)
+                BGSA_SEMI_CASE(24) BGSA_SEMI_CASE(25) BGSA_SEMI_CASE(26) BGSA_SEMI_CASE(28) BGSA_SEMI_CASE(30) BGSA_SEMI_CASE(32)
 #undef BGSA_SEMI_CASE
             default: break;
             }

@@ -654,7 +654,7 @@ def myers_parked_body(nw: int) -> Body:
     return b
 
 
-def myers_semi_body(nw: int) -> Body:
+def myers_semi_body(nw: int, split: int = 0) -> Body:
     """Semi-global Myers (generator -m 0 -s, MyersGenerator.java:56-223): the subject end to end inside the
     query — D[i][0] = 0 for every query row i, result = min over i of D[i][n].  The body is myers_body with
       * carry-in 0 instead of 1 for the HP shift (the row edge D[i][0] - D[i-1][0] = 0), and
@@ -664,7 +664,41 @@ def myers_semi_body(nw: int) -> Body:
         that leave the HP and HN shift chains ARE D[i][n] - D[i-1][n], added to / subtracted from the running
         score with one add-with-carry each, plus one v_min for the best score — 3 instructions per row on top of
         the 10 per word, nothing extracted bit by bit.
-    State: myers_body's, then S[2nw] = D[i][n] (running), S[2nw+1] = its minimum so far."""
+    State: myers_body's, then S[2nw] = D[i][n] (running), S[2nw+1] = its minimum so far.
+    split = K > 0: the two chains in turns over blocks of K words, as myers_body(split=K) — 2K temporaries, which keeps the five Peq
+    planes resident up to 32 words (round 5); the two carries that leave the chains are taken where the LAST block's phases end."""
+    if MYERS_EIGHT and split > 0:
+        b = Body()
+        VP = lambda w: f"S{w * 2}"
+        VN = lambda w: f"S{w * 2 + 1}"
+        RUN, BEST = f"S{2 * nw}", f"S{2 * nw + 1}"
+        blocks = [(lo, min(nw, lo + split)) for lo in range(0, nw, split)]
+        for j, (lo, hi) in enumerate(blocks):
+            first, last = j == 0, j == len(blocks) - 1
+            for w in range(lo, hi):      # phase A: the addition's chain
+                b.AND(f"a{w}", VP(w), f"E{w}")
+                (b.ADD_CO if w == 0 else b.ADDC)(f"m{w}", VP(w), f"a{w}")
+                if w == hi - 1 and not last:
+                    b.SAVECC(0)
+                b.BITOP3(f"a{w}", f"m{w}", VP(w), f"a{w}", lambda s_, vp, a_: s_ ^ vp ^ a_)
+                b.BITOP3(f"m{w}", f"E{w}", VN(w), f"a{w}", lambda e, vn, hn: e | vn | hn)
+                if w == hi - 1 and last:
+                    b.SUBBZ(RUN)             # - the HN bit that left the last column (two instructions behind the chain's last link)
+                if w == hi - 1 and not first:
+                    b.LOADCC(1)              # the HP shift's carry out of the block before (block 0 starts it with carry-in 0: ADD_CO)
+                b.BITOP3(VP(w), f"m{w}", VN(w), VP(w), lambda m, vn, vp: (m & vn) | ~(m | vp))
+            for w in range(lo, hi):      # phase B: HP << 1 across words
+                (b.ADD_CO if w == 0 else b.ADDC)(VP(w), VP(w), VP(w))
+                if w == hi - 1 and not last:
+                    b.SAVECC(1)
+                b.AND(VN(w), f"m{w}", VP(w))
+                if w == hi - 1 and last:
+                    b.ADDCZ(RUN)             # + the HP bit that left the last column (before anything else writes VCC)
+                if w == hi - 1 and not last:
+                    b.LOADCC(0)
+                b.BITOP3(VP(w), f"m{w}", f"a{w}", VP(w), lambda m, hn, hp: (m & hn) | ~(m | hp))
+        b.MINU(BEST, BEST, RUN)
+        return b
     if MYERS_EIGHT:
         # the eight-instruction row (myers_body): the carry that LEAVES the addition chain is [v = 2] of the last column = its HN bit,
         # the one that leaves the HP shift its HP bit — the same two score updates, 8 VALU per word + 3 per row
@@ -742,15 +776,15 @@ def semi_align(peq: np.ndarray, slen: int, nw: int):
     return out, vp
 
 
-def myers_semi_simulate(subjects: np.ndarray, query: np.ndarray, nw: int) -> np.ndarray:
-    """One query against the subjects with myers_semi_body, set up as myers_global_asm_kernel<NW, SEMI> does."""
+def myers_semi_simulate(subjects: np.ndarray, query: np.ndarray, nw: int, body: "Body | None" = None) -> np.ndarray:
+    """One query against the subjects with myers_semi_body (or the given form of it), set up as myers_semi_asm_kernel<NW> does."""
     n, slen = subjects.shape
     peq, vp0 = semi_align(build_peq32(subjects, (slen + 31) // 32), slen, nw)
     st = []
     for w in range(nw):
         st += [np.full(n, vp0[w], np.uint32), np.zeros(n, np.uint32)]
     st += [np.full(n, slen, np.uint32), np.full(n, slen, np.uint32)]     # D[0][n] = n
-    body = myers_semi_body(nw)
+    body = myers_semi_body(nw) if body is None else body
     code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3, ord("N"): 4}
     for ch in query:
         c = code.get(int(ch), 0)

@@ -1186,7 +1186,7 @@ def test_myers_semiglobal_vs_dp(oracle, qlen, slen):
 
 
 def test_myers_semiglobal_kernel_families(oracle):
-    # generated-asm kernels: resident Peq planes up to 800 bp, code planes up to 1024 bp, column blocks beyond — any length
+    # generated-asm kernels: resident Peq planes up to 1024 bp, column blocks beyond — any length
     L = B.lib()
     L.bgsa_hip_select_algorithm(B.ALGO_MYERS)
     L.bgsa_hip_select_alignment(1)
@@ -1194,8 +1194,9 @@ def test_myers_semiglobal_kernel_families(oracle):
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 5).startswith(b"myers_semi_asm_kernel<5>")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 24).startswith(b"myers_semi_asm_kernel<24>")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 25).startswith(b"myers_semi_asm_kernel<25>")
-        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 26).startswith(b"myers_semi_planes_kernel<26>")
-        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 32).startswith(b"myers_semi_planes_kernel<32>")
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 26).startswith(b"myers_semi_asm_kernel<26>")     # round 5: the chains in turns keep
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 31).startswith(b"myers_semi_asm_kernel<32>")     # five Peq planes resident up to 32 words
+        assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 32).startswith(b"myers_semi_asm_kernel<32>")     # (the code planes: BGSA_MYERS_PEQ_MAX_WORDS)
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 33).startswith(b"myers_blocked_kernel<")
         assert L.bgsa_hip_kernel_name(B.ALGO_MYERS, 125).startswith(b"myers_blocked_kernel<18, true, true>")
     finally:
@@ -1315,7 +1316,7 @@ for length, k, groups in ((150, 8, 5), (70, 12, 1), (200, 4, 7), (150, 14, 3), (
     sc[:48] = O.mutate(qc[np.arange(48) % 37], np.arange(48) % (2 * k + 6), 922)
     sc[-3] = O.mutate(qc[5:6], [1], 923)[0]                             # a lone survivor in the last group: regroup pass there too
     assert np.array_equal(B.align_all_pairs(qc, sc, algo=B.ALGO_BANDED, k=k), O.banded64(qc, sc, k)), ("banded odd groups", length, k)
-for slen in (150, 700):   # semi-global Myers: asm kernels by default, the compiler-scheduled one under BGSA_MYERS_IMPL=c
+for slen in (150, 700, 1000):   # semi-global Myers: asm kernels by default (1000 bp: chains in turns; code planes under BGSA_MYERS_PEQ_MAX_WORDS), the compiler-scheduled one under BGSA_MYERS_IMPL=c
     s = O.gen_reads(907 + slen, 70, slen)
     assert np.array_equal(B.align_all_pairs(q, s, algo=B.ALGO_MYERS, semi_global=True), O.dp_edit_semiglobal(q, s)), ("semi", slen)
 # a launch captured into a hipGraph and replayed twice: with the task counter the packer inside the graph zeroes it on every replay

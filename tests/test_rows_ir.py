@@ -585,3 +585,23 @@ def test_schedule_ilp_keeps_the_function_and_separates_dependent_instructions(ma
     assert R.dependent_pairs(body) > nw and R.dependent_pairs(sched) == 0
     assert sched.allocate_temps()[1] <= body.allocate_temps()[1] + 8
     assert sched.valu_count() == body.valu_count() and sched.salu_count() == body.salu_count()
+
+
+@pytest.mark.parametrize("qlen,slen,nw,split", [(300, 1000, 32, 9), (1100, 960, 30, 9), (120, 832, 26, 9), (500, 1024, 32, 9), (200, 150, 5, 2)])
+def test_myers_semi_split_body_matches_the_dp(oracle, qlen, slen, nw, split):
+    """Semi-global Myers with the chains in turns (myers_semi_body(split = K)): the carries that leave the two chains are taken
+    where the LAST block's phases end.  As written and scheduled (what the generator emits for 26 .. 32 words), against the DP."""
+    q = oracle.gen_reads(9100 + qlen, 3, qlen)
+    s = oracle.gen_reads(9200 + slen, 40, slen)
+    if qlen >= slen:
+        for r in range(8):
+            off = (r * 7) % (qlen - slen + 1)
+            s[r] = oracle.mutate(q[r % 3: r % 3 + 1, off: off + slen], [r % 5], r)[0]
+    s[9] = ord("A")
+    q[2] = ord("A")
+    s[10, : slen // 3] = ord("N")
+    want = oracle.dp_edit_semiglobal(q, s)
+    for body in (R.myers_semi_body(nw, split), R.schedule_ilp(R.myers_semi_body(nw, split), 2, 24)):
+        for i in range(q.shape[0]):
+            assert np.array_equal(R.myers_semi_simulate(s, q[i], nw, body), want[i])
+        assert body.valu_count() == 8 * nw + 3 and body.allocate_temps()[1] <= 2 * min(split, nw) + 2
