@@ -284,8 +284,8 @@ __device__ __forceinline__ uint32_t semi_dummy_mask(int aw, int s)
     return d >= 32 ? ~0u : (d <= 0 ? 0u : ((1u << d) - 1u));
 }
 
-// Subjects up to 768 bp (the widths with resident Peq planes): generated asm row loop of myers_semi_body,
-// 8 VALU per word + 3 per row.
+// Subjects up to 1024 bp (resident Peq planes at every width; 26..32 words with the two carry chains in turns): generated asm row loop of
+// myers_semi_body, 8 VALU per word + 3 per row.
 template <int NW>
 __global__ __launch_bounds__(256) void myers_semi_asm_kernel(
     const unsigned char *__restrict__ streams, const uint32_t *__restrict__ peq,
@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) BGSA_PLANES_OCCUPANCY void myers_global_planes
     } while (DYN && task < n_tasks);
 }
 
-// Semi-global for subjects of 769..1024 bp: the code planes right-aligned like the Peq planes of myers_semi_asm_kernel;
+// Semi-global on the code planes (801..1024 bp until round 5; since then those widths run myers_semi_asm_kernel with the chains in turns and
+// this kernel is what BGSA_MYERS_PEQ_MAX_WORDS selects): the code planes right-aligned like the Peq planes of myers_semi_asm_kernel;
 // the unused low columns get code 7 (all three planes set), which MATCH3's truth tables treat as "matches every
 // class" (rows_ir.py: myers_semi_planes_body) — 9 VALU per word + 3 per row, two waves per SIMD at NW = 32.
 template <int NW>
