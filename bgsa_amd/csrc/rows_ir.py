@@ -477,7 +477,9 @@ def schedule_ilp(body: "Body", gap: int = 1, window: int = 24, vcc_dist: int = 3
         def earliest(i):
             t = 0
             for p_, kind in deps[i]:
-                d = need[kind] + (gap if ops[i].kind == "savecc" and kind == "vcc" else 0) - (1 if ops[i].kind == "savecc" and kind == "vcc" else 0)
+                # a scalar read of VCC (SAVECC) has no wait states to keep, but it stalls its wave until the vector pipe has
+                # delivered the carry: keep gap + 1 instructions between it and the link it reads
+                d = gap + 2 if (ops[i].kind == "savecc" and kind == "vcc") else need[kind]
                 t = max(t, pos[p_] + d)
             return t
 
