@@ -712,6 +712,12 @@ def main() -> int:
     # the shader-clock and the reference-clock counters beside the timed kernels.  Off under a profiler.
     profiled = any(name.startswith(("ROCPROF", "ROCP_")) for name in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     use_probe = not args.no_clock_probe and not profiled
+    probe_note = None
+    if use_probe and algo == B.ALGO_MYERS and aligner.wn >= 25 and aligner.wn <= 32:
+        # these kernels hold 253-255 VGPRs at two waves per SIMD: a probe wave finds no register granule beside them and displaces a
+        # workgroup on its CU (25 words: 9,091 -> 9,664 ms with the probes, LABNOTES 5.1; 32 words: 3,953 -> 4,112, round 5)
+        use_probe = False
+        probe_note = "no clock probes beside a kernel that fills the register file (253-255 VGPRs): a probe wave would displace a workgroup"
     L = B.lib()
 
     def probe_start(expected_s):
@@ -827,7 +833,6 @@ def main() -> int:
         elapsed, step_s = timed(gathered_step, args.steps, args.warmup, probe=True)
         gather_timer.cancel()
         clock = clock_box[0]
-        probe_note = None
     else:
         wd.stage = "timed region"
         sampler = PowerSampler().start() if (rank == 0 and os.environ.get("BGSA_BENCH_POWER", "1") != "0") else None
@@ -837,7 +842,6 @@ def main() -> int:
         # The probes must not cost anything.  If the wall time of the timed region is not the kernels' time (events on the launch
         # stream) plus launch overhead, something held the launches back — the probes, on a box where they do not run beside the
         # caller's stream after all — and the region is timed again without them; the line then says so instead of carrying a clock.
-        probe_note = None
         if clock is not None:
             slow = elapsed > 1.25 * kernel_s * args.steps + 0.05
             if dist is not None:
