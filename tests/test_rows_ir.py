@@ -605,3 +605,28 @@ def test_myers_semi_split_body_matches_the_dp(oracle, qlen, slen, nw, split):
         for i in range(q.shape[0]):
             assert np.array_equal(R.myers_semi_simulate(s, q[i], nw, body), want[i])
         assert body.valu_count() == 8 * nw + 3 and body.allocate_temps()[1] <= 2 * min(split, nw) + 2
+
+
+@pytest.mark.parametrize("nw,split", [(32, 9), (30, 8), (8, 3), (5, 2)])
+@pytest.mark.parametrize("balanced", [False, True])
+def test_myers_body_variants_of_the_measurement_builds_are_the_same_function(nw, split, balanced):
+    """The forms only `scripts/build_variant.sh` builds (round 5's A/Bs: the pausing chain parked in a VECTOR register — SAVEV /
+    LOADV —, phases balanced at four instructions per carry link, a minimum link distance in the scheduler) compute what the
+    shipped body computes, on random states for every class, as written and scheduled."""
+    rng = np.random.default_rng(1000 * nw + split + balanced)
+    ref = R.myers_body(nw)
+    forms = [R.myers_body(nw, 1, split=split, park=park, balanced=balanced) for park in ("sgpr", "vgpr")]
+    forms += [R.schedule_ilp(f, 2, 24, 4) for f in forms]
+    for body in forms:
+        for _ in range(3):
+            vp = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) for _ in range(nw)]
+            vn = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) & ~vp[w] for w in range(nw)]
+            eq = [rng.integers(0, 2 ** 32, 64, dtype=np.uint32) for _ in range(nw)]
+            s1 = [x.copy() for w in range(nw) for x in (vp[w], vn[w])]
+            s2 = [x.copy() for x in s1]
+            ref.simulate(s1, eq)
+            body.simulate(s2, eq)
+            assert all(np.array_equal(a, b) for a, b in zip(s1, s2))
+    blocks = -(-nw // split)
+    assert forms[1].valu_count() == 8 * nw + 4 * (blocks - 1) and forms[1].salu_count() == 1      # vector park: VALU instead of scalar moves
+    assert forms[0].valu_count() == 8 * nw and forms[0].salu_count() == 4 * (blocks - 1) + 1
