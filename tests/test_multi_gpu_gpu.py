@@ -231,6 +231,27 @@ def test_bench_line_carries_the_sustained_clock_without_paying_for_it():
     assert c["probe_seconds"] < 2.0 * r["ms_per_step"] * 4 / 1e3 + 0.5
     assert r["roofline"]["issued"]["frac_at_sustained_clock"] >= r["roofline"]["issued"]["frac"] * 0.99
     assert r["ranks_seen"] == 1 and r["gather_ok"] is None and r["roofline"]["traffic_model"]["query_tile"] >= 1
+    # the utilisation as scalars of `roofline`, the clock and (where the driver's hwmon files are readable) the power beside them
+    ro = r["roofline"]
+    assert ro["issued_frac"] == ro["issued"]["frac"] and ro["issued_frac_sustained"] == ro["issued"]["frac_at_sustained_clock"]
+    assert ro["valu_per_wave_row"] and ro["sustained_mhz"] == c["sustained_mhz"] and r["scaling"] == "strong"
+    assert r["power"] is None or (r["power"]["samples"] >= 1 and ro["watts_mean"] == r["power"]["watts_mean"] and 50 < ro["watts_mean"] < 2000)
+
+
+def test_no_clock_probes_beside_a_kernel_that_fills_the_register_file():
+    """The 30 / 32-word Myers kernels hold 253-255 VGPRs at two waves per SIMD: a probe wave finds no register granule beside them and
+    would displace a workgroup (config 5: 3,953 -> 4,112 ms).  The line then says why it carries no clock instead of paying for one."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--config", "5", "--steps", "2", "--warmup", "1", "--nq", "64", "--ns", "65536",
+           "--no-cpu-baseline", "--no-total"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["config"]["kernel"].startswith("myers_global_asm_kernel<32, 1>") and r["value"] > 0
+    assert r["clock"]["sustained_mhz"] is None and "register file" in r["clock"]["note"]
+    assert r["roofline"]["issued_frac"] and r["roofline"]["issued_frac_sustained"] is None and r["roofline"]["valu_per_wave_row"] == 256
 
 
 def test_config5_eight_shards_one_after_another_equal_the_whole_bucket():
