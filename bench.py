@@ -10,7 +10,7 @@ blocks) are resident in HBM before the timed region.  The job is the SAME at eve
   * N = 1: the whole bucket on the one GPU, one launch per step, scores stay in HBM (nothing to gather);
   * N > 1 (one rank per GPU, torch.distributed / RCCL): the bucket is cut into contiguous slices by plan_shards (the KNC
     backend's dispatch_task, BGSA_KNC/global.c:374-431), the query set is broadcast from rank 0 once, and a step is, per block of
-    GATHER_BLOCK_ROWS queries, the kernel on the rank's slice + its tile handed to the streamed gather (ScoreGatherStream: a side
+    gather_block_rows(nq) queries (1,000 for the 10k-query configs), the kernel on the rank's slice + its tile handed to the streamed gather (ScoreGatherStream: a side
     stream sends it to rank 0 while the next block is scored; cal_mic.c:121-147, 535-536), then drain() — the gather is INSIDE the
     timed region, so `value` is what the node delivers to rank 0, not what its kernels could.  Beside it: `kernel_only` (one launch
     per pass, no transfer: the reference's "cal"), `gather_blocks_of_100` (the same mechanism in the reference's block size),
@@ -69,7 +69,18 @@ CONFIGS = {
 # per GPU and point-to-point xGMI links the block is sized for the transfer: 1,000 rows = 250 MB per peer and block at N = 8
 # (fewer, larger transfers; a launch of 1,000 x 125k pairs holds 60 tasks per wave slot where 100 rows hold six).  The line
 # carries the reference-sized blocks beside it (`gather_blocks_of_100`).  BGSA_BENCH_BLOCK_ROWS overrides.
-GATHER_BLOCK_ROWS = int(os.environ.get("BGSA_BENCH_BLOCK_ROWS", "1000"))
+GATHER_BLOCK_ROWS_MAX = 1000
+
+
+def gather_block_rows(nq: int) -> int:
+    """Rows per block of the N > 1 timed region: BGSA_BENCH_BLOCK_ROWS if set; else 1,000 — but never fewer than ten blocks per step
+    (the gather of block i travels beside the kernel of block i + 1: a step of one block would overlap nothing; config 5's 1,000
+    queries run as ten blocks of the reference's 100) and never below the reference's REF_BUCKET_COUNT."""
+    e = os.environ.get("BGSA_BENCH_BLOCK_ROWS")
+    if e:
+        return max(1, int(e))
+    return min(GATHER_BLOCK_ROWS_MAX, max(REF_BUCKET_COUNT, -(-nq // 10)))
+
 
 # Subject mixes of the banded filter (config 3).  Its work is data dependent: a wave stops as soon as every
 # one of its 64 lanes is past the error limit, so the rate depends on how many pairs survive and how they
@@ -775,6 +786,7 @@ def main() -> int:
     one_launch = lambda: aligner.score(0, nq, out=out)     # noqa: E731  every query against the rank's resident subjects
     kernel_only = None
     gs = None
+    GATHER_BLOCK_ROWS = gather_block_rows(nq)
     n_blocks_step = -(-nq // GATHER_BLOCK_ROWS)
     if world > 1:
         # ---- N > 1.  The job is the SAME bucket as at N = 1, cut over the ranks; what has to be true at the end of a step is

@@ -142,4 +142,7 @@ def test_every_config_is_one_job_at_every_n():
     finally:
         wd.cancel()
     assert stub["scaling"] == "strong" and stub["config"]["workload"] == bench.CONFIGS[2][1] and stub["n_gpus"] == 4
-    assert bench.GATHER_BLOCK_ROWS >= bench.REF_BUCKET_COUNT
+    # rows per block of the sharded run's timed region: 1,000 for the 10k-query configs, ten blocks of 100 for config 5's 1,000 queries,
+    # never below the reference's block
+    assert bench.gather_block_rows(10_000) == 1000 and bench.gather_block_rows(1_000) == 100 and bench.gather_block_rows(300) == 100
+    assert bench.gather_block_rows(50_000) == 1000 and bench.REF_BUCKET_COUNT == 100
