@@ -563,11 +563,14 @@ def side_config(cfg_id, dev, L, nq=None, ns=None, passes=2, mix="planted", rank=
     a.score(0, nq, out=out)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(passes)]
+    # power and clock of the card while the passes run (hwmon files, no probe waves here): one GPU, rank 0 only
+    sampler = PowerSampler(0.05).start() if (dist is None and rank == 0 and os.environ.get("BGSA_BENCH_POWER", "1") != "0") else None
     for e0, e1 in ev:
         e0.record()
         a.score(0, nq, out=out)
         e1.record()
     torch.cuda.synchronize()
+    side_power = sampler.stop() if sampler else None
     a.check_faults()
     kernel_s = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) / 1e3
     cells = float(nq) * ns * length * length
@@ -599,7 +602,15 @@ def side_config(cfg_id, dev, L, nq=None, ns=None, passes=2, mix="planted", rank=
         entry["issued"]["valu_per_nominal_wave_row"] = round(pmc["SQ_INSTS_VALU"] / (float(nq) * (ns_pad // 64) * length), 3)
     elif vpr and exact:
         entry["issued"]["valu_per_row"] = vpr
-    entry.update(flat_issued(entry["issued"]))  # issued_frac_sustained stays None: the clock probes run beside the headline's timed region only
+    entry["power"] = side_power
+    if side_power and side_power.get("sclk_mhz_mean") and entry["issued"].get("frac"):
+        # the clock probes run beside the headline's timed region only; here the sustained clock is the driver's own reading of the
+        # card's shader clock, sampled on the host during the passes (about 1.5 % above what the probe waves measure under config 2)
+        entry["issued"]["frac_at_sustained_clock"] = round(entry["issued"]["frac"] * 2400.0 / side_power["sclk_mhz_mean"], 4)
+        entry["issued"]["sustained_clock_source"] = "hwmon freq1_input, mean over the timed passes"
+    entry.update(flat_issued(entry["issued"]))
+    entry["sustained_mhz"] = side_power.get("sclk_mhz_mean") if side_power else None
+    entry["watts_mean"] = side_power.get("watts_mean") if side_power else None
     if cpu:
         # the reference's own CPU path for this config on this node's host cores, in the same run (north_star): 64 threads —
         # the count that won every thread sweep of rounds 3-4 on these hosts — by the reference's cal timer (cal_cpu.c:111-118,472)
@@ -953,6 +964,9 @@ def main() -> int:
             issued["pmc_file"] = pmc_src
             if clock:    # the same instructions against the clock this box really held: tells a slow box from a slower kernel
                 issued["frac_at_sustained_clock"] = round(issued["frac"] * 2400.0 / clock["sustained_mhz"], 4)
+            elif power and power.get("sclk_mhz_mean"):   # no probe waves beside this kernel: the driver's own reading of the card's clock
+                issued["frac_at_sustained_clock"] = round(issued["frac"] * 2400.0 / power["sclk_mhz_mean"], 4)
+                issued["sustained_clock_source"] = "hwmon freq1_input, mean over the timed region"
         traffic = None
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM (128-B requests tallied at 64 B); KB units
@@ -1005,7 +1019,8 @@ def main() -> int:
                 # the utilisation figures as scalars of this object (a parser that keeps only scalars keeps these): VALU instructions
                 # issued x 64 lanes / kernel time / peak, at the nominal and at the sustained clock; instructions per (query row, wave)
                 **flat_issued(issued),
-                "sustained_mhz": clock["sustained_mhz"] if clock else None,       # the clock the chip held under the timed kernels (probe waves)
+                # the clock the chip held under the timed kernels: probe waves; the driver's hwmon reading where no probe runs
+                "sustained_mhz": clock["sustained_mhz"] if clock else (power.get("sclk_mhz_mean") if power else None),
                 "watts_mean": power["watts_mean"] if power else None,            # and the power it drew (hwmon files, host-side sampling)
                 "issued": issued,
                 "traffic": traffic,
@@ -1259,7 +1274,9 @@ def main() -> int:
                 result["roofline"][f"cfg{cid}_gcups"] = e["gcups"]
                 result["roofline"][f"cfg{cid}_kernel_ms"] = e["kernel_ms"]
                 result["roofline"][f"cfg{cid}_issued_frac"] = e["issued_frac"]
+                result["roofline"][f"cfg{cid}_issued_frac_sustained"] = e["issued_frac_sustained"]
                 result["roofline"][f"cfg{cid}_valu_per_wave_row"] = e["valu_per_wave_row"]
+                result["roofline"][f"cfg{cid}_watts_mean"] = e["watts_mean"]
         if not args.no_cpu_baseline and world == 1 and not custom_scores:  # the reference commits 2/-3/-5 only
             wd.stage = "cpu_baseline leg"
             cq, cs = (int(x) for x in args.cpu_sample.split("x"))

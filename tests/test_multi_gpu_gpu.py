@@ -207,6 +207,11 @@ def test_bench_line_carries_the_other_baseline_configs():
         assert "SIZE OVERRIDDEN" in e["workload"] and isinstance(e["checksum"], int)
     assert oc["3"]["banded_mix"]["name"] == "planted" and 0 < oc["3"]["banded_mix"]["fraction"] < 0.01
     assert oc["4"]["issued"]["frac"] and oc["5"]["issued"]["frac"]          # exact generator counts at any size
+    for cid in ("3", "4", "5"):     # the same scalars in every entry, mirrored into `roofline` (power / hwmon clock where readable)
+        e = oc[cid]
+        assert all(name in e for name in ("issued_frac", "issued_frac_sustained", "valu_per_wave_row", "sustained_mhz", "watts_mean"))
+        assert r["roofline"][f"cfg{cid}_gcups"] == e["gcups"] and r["roofline"][f"cfg{cid}_issued_frac"] == e["issued_frac"]
+        assert r["roofline"][f"cfg{cid}_watts_mean"] == e["watts_mean"]
 
 
 def test_bench_line_carries_the_sustained_clock_without_paying_for_it():
@@ -249,7 +254,14 @@ def test_no_clock_probes_beside_a_kernel_that_fills_the_register_file():
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert r["config"]["kernel"].startswith("myers_global_asm_kernel<32, 1>") and r["value"] > 0
     assert r["clock"]["sustained_mhz"] is None and "register file" in r["clock"]["note"]
-    assert r["roofline"]["issued_frac"] and r["roofline"]["issued_frac_sustained"] is None and r["roofline"]["valu_per_wave_row"] == 256
+    ro = r["roofline"]
+    assert ro["issued_frac"] and ro["valu_per_wave_row"] == 256
+    # without probe waves the sustained clock is the driver's own reading of the card (hwmon), where its files are readable
+    if r["power"] and r["power"]["sclk_mhz_mean"]:
+        assert ro["sustained_mhz"] == r["power"]["sclk_mhz_mean"] and "hwmon" in ro["issued"]["sustained_clock_source"]
+        assert ro["issued_frac"] * 0.95 <= ro["issued_frac_sustained"] <= ro["issued_frac"] * 2.5
+    else:
+        assert ro["issued_frac_sustained"] is None
 
 
 def test_config5_eight_shards_one_after_another_equal_the_whole_bucket():
