@@ -393,6 +393,26 @@ def test_banded_reference_host_pipeline_on_the_gpu_library(tmp_path, name):
     assert "GCUPS" in report
 
 
+BANDED_HIP_COARSE = ROOT / "oracle" / "_ref" / "banded_hip_coarse" / "aligner"
+
+
+@pytest.mark.parametrize("name", ["f8_banded_k8_150", "f8_banded_k4_150", "f8_banded_k16_150", "f8_banded_k8_len500"])
+def test_banded_reference_host_pipeline_through_the_coarse_seam(tmp_path, name, monkeypatch):
+    """banded/BGSA_CPU's own main.c (-k) / file.c / thread.c and its cal_cpu.c minus the grid function (derive_cal_hip.py): cpu_cal
+    lands in hip_cal_align_score with the reference's word_num convention, 64-bit cpu_read_t and int8 results — one launch per block."""
+    if not BANDED_HIP_COARSE.exists():
+        pytest.skip("oracle/_ref/banded_hip_coarse not built (needs /root/reference at build time)")
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "BANDED_HIP", BANDED_HIP_COARSE)     # _run_banded_host starts whatever BANDED_HIP names
+    g = load_golden(name)
+    got, report = _run_banded_host(tmp_path, g, g["k"])
+    assert np.array_equal(got, g["scores"])
+    assert "GCUPS" in report
+    undefined = {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--undefined-only", str(BANDED_HIP_COARSE)], capture_output=True,
+                                                         text=True, check=True).stdout.splitlines() if ln.strip()}
+    assert "hip_cal_align_score" in undefined and "align_hip" not in undefined
+
+
 def test_banded_reference_host_default_threshold(tmp_path, oracle):
     # no -k: banded/BGSA_CPU/main.c:43 sets threshold = CPU_WORD_SIZE / 2 - 1 = 31 (the 64-bit band kernel);
     # the reference's word_num for k = 31 is smaller than the device layout, so the seam re-pitches it
